@@ -1,0 +1,112 @@
+"""ctypes binding of libdaliid_hip.so (the C ABI declared in include/daliid.h).
+
+Fails loudly: a missing library raises at first use, a non-zero status raises ``DaliError`` carrying
+``dali_last_error()``.  PyTorch is used here only to obtain device pointers and the current HIP stream.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdaliid_hip.so")
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+
+class DaliError(RuntimeError):
+    pass
+
+
+# name -> argtypes; every function returns int status unless listed in _RESTYPES
+_SIGNATURES = {
+    "dali_version": [],
+    "dali_last_error": [],
+    "dali_ctx_create": [c_int, ctypes.POINTER(c_void_p)],
+    "dali_ctx_destroy": [c_void_p],
+    "dali_ctx_reserve": [c_void_p, c_size_t],
+    "dali_l2norm_rows": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
+    "dali_l2norm_rows_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "dali_pairdist": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "dali_pairdist_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "dali_pairdist_prepared": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                               c_int, c_int, c_void_p],
+    "dali_rank_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+}
+_RESTYPES = {"dali_last_error": ctypes.c_char_p}
+
+_lock = threading.Lock()
+_lib = None
+_ctxs = {}
+
+
+def exported_symbols():
+    """Names include/daliid.h declares (used by the CPU symbol-export test)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load the shared library (no GPU needed for loading)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise DaliError(
+                        "libdaliid_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C daliid_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+                L = ctypes.CDLL(LIB_PATH)
+                for name, argtypes in _SIGNATURES.items():
+                    fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+                    fn.argtypes = argtypes
+                    fn.restype = _RESTYPES.get(name, c_int)
+                _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().dali_last_error().decode("utf-8", "replace")
+
+
+def check(status, what=""):
+    if status != 0:
+        raise DaliError("%s failed with status %d: %s" % (what or "libdaliid_hip call", status, last_error()))
+
+
+def ctx(device=None):
+    """One dali_ctx per device ordinal, created on first use."""
+    if not torch.cuda.is_available():
+        raise DaliError("daliid_amd needs a gfx950 GPU (torch.cuda.is_available() is False); there is no CPU path")
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device(device).index if not isinstance(device, int) else device
+    if device is None:
+        device = torch.cuda.current_device()
+    c = _ctxs.get(device)
+    if c is None:
+        with _lock:
+            c = _ctxs.get(device)
+            if c is None:
+                h = c_void_p()
+                check(lib().dali_ctx_create(device, ctypes.byref(h)), "dali_ctx_create")
+                c = _ctxs[device] = h
+    return c
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous CUDA(HIP) tensor, validated."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise DaliError("%s must live on the GPU" % name)
+    if not t.is_contiguous():
+        raise DaliError("%s must be contiguous" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise DaliError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return c_void_p(t.data_ptr())

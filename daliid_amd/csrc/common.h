@@ -1,0 +1,75 @@
+// common.h -- shared host/device helpers for libdaliid_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/daliid.h"
+
+namespace dali {
+
+void set_error(const char* fmt, ...);
+
+}  // namespace dali
+
+struct dali_ctx {
+    int device;
+    int num_cus;
+    void* ws;          // grow-only device workspace
+    size_t ws_bytes;
+};
+
+namespace dali {
+// Returns a workspace pointer of at least `bytes` (256-B aligned) or nullptr (+ error set).
+void* workspace(dali_ctx* ctx, size_t bytes);
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+}  // namespace dali
+
+#define DALI_HIP(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            dali::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return DALI_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+#define DALI_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            dali::set_error(__VA_ARGS__);  \
+            return DALI_ERR_INVALID;       \
+        }                                  \
+    } while (0)
+
+#define DALI_LAUNCH_CHECK() DALI_HIP(hipGetLastError())
+
+// ---- device helpers -------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// round-to-nearest-even f32 -> bf16 bits via the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

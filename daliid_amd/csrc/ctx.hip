@@ -1,0 +1,73 @@
+// ctx.hip -- context, error string and workspace of libdaliid_hip.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+#include <string_view>
+
+namespace dali {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+void* workspace(dali_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return ctx->ws;
+    // grow-only; the old block may still be in use by enqueued kernels -> drain first
+    if (hipDeviceSynchronize() != hipSuccess) { set_error("workspace: device synchronize failed"); return nullptr; }
+    if (ctx->ws) { (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        set_error("workspace: hipMalloc(%zu) failed", want);
+        return nullptr;
+    }
+    ctx->ws = p;
+    ctx->ws_bytes = want;
+    return p;
+}
+
+}  // namespace dali
+
+extern "C" int dali_version(void) { return 100; }
+
+extern "C" const char* dali_last_error(void) { return dali::g_err; }
+
+extern "C" int dali_ctx_create(int device, dali_ctx** out) {
+    DALI_REQUIRE(out != nullptr, "dali_ctx_create: out is null");
+    int ndev = 0;
+    DALI_HIP(hipGetDeviceCount(&ndev));
+    DALI_REQUIRE(device >= 0 && device < ndev, "dali_ctx_create: device %d not in [0,%d)", device, ndev);
+    DALI_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    DALI_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string_view(prop.gcnArchName).substr(0, 6) != "gfx950") {
+        dali::set_error("dali_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return DALI_ERR_UNSUPPORTED;
+    }
+    dali_ctx* c = new (std::nothrow) dali_ctx();
+    if (!c) { dali::set_error("dali_ctx_create: out of host memory"); return DALI_ERR_NOMEM; }
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    *out = c;
+    return DALI_OK;
+}
+
+extern "C" int dali_ctx_destroy(dali_ctx* ctx) {
+    if (!ctx) return DALI_OK;
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    delete ctx;
+    return DALI_OK;
+}
+
+extern "C" int dali_ctx_reserve(dali_ctx* ctx, size_t bytes) {
+    DALI_REQUIRE(ctx != nullptr, "dali_ctx_reserve: null ctx");
+    return dali::workspace(ctx, bytes) ? DALI_OK : DALI_ERR_NOMEM;
+}

@@ -1,0 +1,429 @@
+// eval.hip -- evaluation path of validateModels.validate (validateModels.py:35-76):
+//   row L2 normalisation (:41-42), distmat = 1 - q @ g.T (:47) on MFMA, and the market1501 CMC/mAP
+//   arithmetic of torchreid.metrics.evaluate_rank (:68) without a full row sort.
+#include "gemm_tile.h"
+
+namespace dali {
+
+// ------------------------------------------------------------------------------------------------
+// Row pre-pass: one wave64 per row.  Optionally normalises (y = x / (|x| + eps)), emits the bf16 "hi"
+// part and the bf16 residual "lo" (y - hi) zero-padded to Kp columns, |y|^2, and/or the fp32 row.
+// HBM-bound: reads 4 B/elem once, writes 2-4 B/elem.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, int n, int d, int Kp,
+                                                         int normalize, float eps, uint16_t* __restrict__ hi,
+                                                         uint16_t* __restrict__ lo, float* __restrict__ sq,
+                                                         float* __restrict__ yout, float* __restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* xr = x + (size_t)row * d;
+    float ss = 0.f;
+    const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec) {
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int c = lane; c < d; c += 64) { const float v = xr[c]; ss += v * v; }
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    const float den = normalize ? (nrm + eps) : 1.0f;
+    if (lane == 0) {
+        if (norms) norms[row] = nrm;
+        if (sq) sq[row] = normalize ? (ss / (den * den)) : ss;
+    }
+    // second sweep (the row is L1/L2 resident): write outputs
+    for (int c = lane * 4; c < Kp; c += 256) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (c + t < d) ? xr[c + t] / den : 0.f;
+        if (yout) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (c + t < d) yout[(size_t)row * d + c + t] = v[t];
+        }
+        if (hi) {
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                h[t] = f32_to_bf16_bits(v[t]);
+                l[t] = f32_to_bf16_bits(v[t] - bf16_bits_to_f32(h[t]));
+            }
+            uint2 hv = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *reinterpret_cast<uint2*>(hi + (size_t)row * Kp + c) = hv;
+            if (lo) {
+                uint2 lv = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                *reinterpret_cast<uint2*>(lo + (size_t)row * Kp + c) = lv;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          int n, int d, float eps, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* xr = x + (size_t)row * d;
+    const float* gr = dy + (size_t)row * d;
+    float ss = 0.f, xg = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = xr[c]; ss += v * v; xg += v * gr[c]; }
+    ss = wave_sum(ss); xg = wave_sum(xg);
+    const float nrm = sqrtf(ss), den = nrm + eps;
+    const float a = 1.0f / den;
+    const float b = (nrm > 0.f) ? xg / (nrm * den * den) : 0.f;
+    for (int c = lane; c < d; c += 64) dx[(size_t)row * d + c] = gr[c] * a - xr[c] * b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair distance: out[q][g] = 1 - Q[q].G[g]   (or |q|^2 + |g|^2 - 2 q.g)
+// MFMA rows (m) = gallery, MFMA columns (n) = query, so each lane's 4 accumulator registers are 4
+// consecutive gallery entries of one query row: one 16-byte store.
+// Algorithmic work: 2*d FLOP per pair (x3 MFMA issue in split-bf16 mode); bound: MFMA.
+// ------------------------------------------------------------------------------------------------
+template <int NPROD>
+struct PairCfg { using type = GemmCfg<128, 128, (NPROD == 3 ? 2 : 1), (NPROD == 3 ? 2 : 1), NPROD>; };
+
+struct RowLoader {
+    const uint16_t* p0; const uint16_t* p1;
+    int row0, nrows, Kp;
+    __device__ __forceinline__ uint4 operator()(int arr, int row, int kt, int kc) const {
+        const int r = row0 + row;
+        if (r >= nrows) return make_uint4(0, 0, 0, 0);
+        const uint16_t* p = arr ? p1 : p0;
+        return *reinterpret_cast<const uint4*>(p + (size_t)r * Kp + kt * 32 + kc * 8);
+    }
+};
+
+template <int NPROD>
+__global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restrict__ Ghi, const uint16_t* __restrict__ Glo,
+                                                       const uint16_t* __restrict__ Qhi, const uint16_t* __restrict__ Qlo,
+                                                       const float* __restrict__ gsq, const float* __restrict__ qsq,
+                                                       int ng, int nq, int Kp, int metric, float* __restrict__ out,
+                                                       int tiles_m, int tiles_n) {
+    using Cfg = typename PairCfg<NPROD>::type;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    f32x4_t acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    RowLoader la{Ghi, Glo, tm * Cfg::TM, ng, Kp};
+    RowLoader lb{Qhi, Qlo, tn * Cfg::TN, nq, Kp};
+    gemm_mainloop<Cfg>(acc, la, lb, Kp / 32, smem);
+
+    int mb, nb;
+    acc_coords<Cfg>(mb, nb);
+    const bool vec_ok = (ng & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < Cfg::FN; ++j) {
+        const int q = tn * Cfg::TN + nb + j * 16;
+        if (q >= nq) continue;
+        const float qq = (metric == DALI_METRIC_L2SQ) ? qsq[q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i) {
+            const int g0 = tm * Cfg::TM + mb + i * 16;
+            if (g0 >= ng) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dot = acc[i][j][r];
+                if (metric == DALI_METRIC_L2SQ) {
+                    const float gg = (g0 + r < ng) ? gsq[g0 + r] : 0.f;
+                    v[r] = qq + gg - 2.0f * dot;
+                } else {
+                    v[r] = 1.0f - dot;
+                }
+            }
+            float* o = out + (size_t)q * ng + g0;
+            if (vec_ok && g0 + 3 < ng) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (g0 + r < ng) o[r] = v[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// market1501 ranking without a row sort.  One 256-thread block per query.
+//   kept(g)  = !(g_pid == q_pid && g_cam == q_cam)                  (junk removal)
+//   match(g) = kept(g) && g_pid == q_pid
+// Sort the matches by key (dist, index) in LDS (bitonic).  Every kept gallery entry is binned by the
+// number of matches with a smaller key (binary search); with c[b] the bin counts,
+//   position (1-based, among kept) of the j-th match = c[0] + ... + c[j]
+//   AP = mean_j (j+1) / position_j ,  first-hit rank = c[0] - 1.
+// Reads the distmat row once (coalesced): HBM-bound, 4 bytes per pair.
+// ------------------------------------------------------------------------------------------------
+constexpr int RANK_PMAX = 4096;
+
+__device__ __forceinline__ bool key_less(float da, int ia, float db, int ib) {
+    return da < db || (da == db && ia < ib);
+}
+
+__global__ __launch_bounds__(256) void rank_query_kernel(const float* __restrict__ distmat, const int32_t* __restrict__ q_pids,
+                                                          const int32_t* __restrict__ g_pids, const int32_t* __restrict__ q_cams,
+                                                          const int32_t* __restrict__ g_cams, int nq, int ng,
+                                                          float* __restrict__ ap_out, int32_t* __restrict__ first_rank,
+                                                          int32_t* __restrict__ status) {
+    __shared__ float s_d[RANK_PMAX];
+    __shared__ int s_i[RANK_PMAX];
+    __shared__ int s_cnt[RANK_PMAX + 1];
+    __shared__ int s_n;
+    __shared__ float s_red[4];
+    __shared__ int s_scan[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* drow = distmat + (size_t)q * ng;
+    const int qp = q_pids[q], qc = q_cams[q];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // 1. collect matches
+    for (int g = tid; g < ng; g += 256) {
+        if (g_pids[g] == qp && g_cams[g] != qc) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < RANK_PMAX) { s_d[slot] = drow[g]; s_i[slot] = g; }
+        }
+    }
+    __syncthreads();
+    const int np = s_n;
+    if (np == 0) {
+        if (tid == 0) { ap_out[q] = 0.f; first_rank[q] = -1; }
+        return;
+    }
+    if (np > RANK_PMAX) {
+        if (tid == 0) { atomicMax(status, 1); ap_out[q] = 0.f; first_rank[q] = -1; }
+        return;
+    }
+    int npad = 1;
+    while (npad < np) npad <<= 1;
+    for (int t = np + tid; t < npad; t += 256) { s_d[t] = __builtin_inff(); s_i[t] = 0x7fffffff; }
+    for (int t = tid; t <= np; t += 256) s_cnt[t] = 0;
+    __syncthreads();
+    // 2. bitonic sort of (dist, idx)
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < npad; t += 256) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const bool up = (t & k) == 0;
+                    const float da = s_d[t], db = s_d[p];
+                    const int ia = s_i[t], ib = s_i[p];
+                    const bool swap = up ? key_less(db, ib, da, ia) : key_less(da, ia, db, ib);
+                    if (swap) { s_d[t] = db; s_d[p] = da; s_i[t] = ib; s_i[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 3. bin every kept gallery entry
+    const float last_d = s_d[np - 1];
+    const int last_i = s_i[np - 1];
+    for (int g = tid; g < ng; g += 256) {
+        const float d = drow[g];
+        if (g_pids[g] == qp && g_cams[g] == qc) continue;          // junk
+        if (key_less(last_d, last_i, d, g)) continue;                 // beyond the last match: affects no position
+        int lo = 0, hi = np;                                          // lower bound: #matches with key < (d,g)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (key_less(s_d[mid], s_i[mid], d, g)) lo = mid + 1; else hi = mid;
+        }
+        atomicAdd(&s_cnt[lo], 1);
+    }
+    __syncthreads();
+    // 4. inclusive scan of the bins + AP (sequential chunks of 256)
+    float ap_part = 0.f;
+    int carry = 0;
+    for (int base = 0; base < np; base += 256) {
+        const int t = base + tid;
+        const int v = (t < np) ? s_cnt[t] : 0;
+        s_scan[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int add = (tid >= o) ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        const int pos = carry + s_scan[tid];
+        if (t < np) ap_part += (float)(t + 1) / (float)pos;
+        if (t == 0) first_rank[q] = pos - 1;
+        carry += s_scan[255];
+        __syncthreads();
+    }
+    ap_part = wave_sum(ap_part);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ap_part;
+    __syncthreads();
+    if (tid == 0) ap_out[q] = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)np;
+}
+
+// Single-block deterministic reduction: CMC curve + mAP over valid queries.
+__global__ __launch_bounds__(256) void rank_reduce_kernel(const float* __restrict__ ap, const int32_t* __restrict__ first_rank,
+                                                           int nq, int max_rank, float* __restrict__ cmc, float* __restrict__ mAP,
+                                                           double* __restrict__ map64, int32_t* __restrict__ num_valid) {
+    __shared__ double s_sum[256];
+    __shared__ int s_valid[256];
+    __shared__ int s_hist[1024];
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 1024; t += 256) s_hist[t] = 0;
+    __syncthreads();
+    double s = 0.0;
+    int nv = 0;
+    for (int q = tid; q < nq; q += 256) {
+        const int fr = first_rank[q];
+        if (fr >= 0) {
+            s += (double)ap[q];
+            ++nv;
+            if (fr < max_rank) atomicAdd(&s_hist[fr], 1);
+        }
+    }
+    s_sum[tid] = s; s_valid[tid] = nv;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s_sum[tid] += s_sum[tid + o]; s_valid[tid] += s_valid[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int n = s_valid[0];
+        num_valid[0] = n;
+        const double m = n > 0 ? s_sum[0] / (double)n : 0.0;
+        mAP[0] = (float)m;
+        if (map64) map64[0] = m;
+        int run = 0;
+        for (int k = 0; k < max_rank; ++k) {
+            run += s_hist[k];
+            cmc[k] = n > 0 ? (float)((double)run / (double)n) : 0.f;
+        }
+    }
+}
+
+}  // namespace dali
+
+using namespace dali;
+
+extern "C" int dali_l2norm_rows(dali_ctx* ctx, void* stream, const float* x, int n, int d, float eps, float* y,
+                                float* norms) {
+    DALI_REQUIRE(ctx && x && y, "dali_l2norm_rows: null argument");
+    DALI_REQUIRE(n >= 0 && d > 0, "dali_l2norm_rows: bad shape n=%d d=%d", n, d);
+    if (n == 0) return DALI_OK;
+    hipLaunchKernelGGL(rows_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, n, d, (d + 3) & ~3, 1, eps,
+                       (uint16_t*)nullptr, (uint16_t*)nullptr, (float*)nullptr, y, norms);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+extern "C" int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x, const float* dy, int n, int d,
+                                    float eps, float* dx) {
+    DALI_REQUIRE(ctx && x && dy && dx, "dali_l2norm_rows_bwd: null argument");
+    DALI_REQUIRE(n >= 0 && d > 0, "dali_l2norm_rows_bwd: bad shape n=%d d=%d", n, d);
+    if (n == 0) return DALI_OK;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, n, d, eps, dx);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+static int launch_pairdist(hipStream_t st, const uint16_t* ghi, const uint16_t* glo, const float* gsq,
+                           const uint16_t* qhi, const uint16_t* qlo, const float* qsq, int nq, int ng, int Kp,
+                           int metric, bool split, float* out) {
+    const int tiles_m = (ng + 127) / 128, tiles_n = (nq + 127) / 128;
+    const int grid = xcd_tile_grid(tiles_m, tiles_n);
+    if (split) {
+        using Cfg = PairCfg<3>::type;
+        DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_kernel<3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        hipLaunchKernelGGL(pairdist_kernel<3>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, ghi, glo, qhi, qlo, gsq, qsq, ng, nq,
+                           Kp, metric, out, tiles_m, tiles_n);
+    } else {
+        using Cfg = PairCfg<1>::type;
+        hipLaunchKernelGGL(pairdist_kernel<1>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, ghi, ghi, qhi, qhi, gsq, qsq, ng, nq,
+                           Kp, metric, out, tiles_m, tiles_n);
+    }
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+extern "C" int dali_pairdist_prepare(dali_ctx* ctx, void* stream, const float* X, int n, int d, int normalize,
+                                     uint16_t* hi, uint16_t* lo, float* sq) {
+    DALI_REQUIRE(ctx && X && hi && sq, "dali_pairdist_prepare: null argument");
+    DALI_REQUIRE(n >= 0 && d > 0, "dali_pairdist_prepare: bad shape n=%d d=%d", n, d);
+    DALI_REQUIRE((reinterpret_cast<uintptr_t>(hi) & 15) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15) == 0,
+                 "dali_pairdist_prepare: hi/lo must be 16-byte aligned");
+    if (n == 0) return DALI_OK;
+    const int Kp = (d + 31) & ~31;
+    hipLaunchKernelGGL(rows_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, n, d, Kp, normalize, 0.0f,
+                       hi, lo, sq, (float*)nullptr, (float*)nullptr);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+extern "C" int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const uint16_t* q_hi, const uint16_t* q_lo,
+                                      const float* q_sq, const uint16_t* g_hi, const uint16_t* g_lo, const float* g_sq,
+                                      int nq, int ng, int d, int metric, float* out) {
+    DALI_REQUIRE(ctx && q_hi && g_hi && q_sq && g_sq && out, "dali_pairdist_prepared: null argument");
+    DALI_REQUIRE((q_lo == nullptr) == (g_lo == nullptr), "dali_pairdist_prepared: q_lo and g_lo must both be set or both null");
+    DALI_REQUIRE(nq >= 0 && ng >= 0 && d > 0, "dali_pairdist_prepared: bad shape nq=%d ng=%d d=%d", nq, ng, d);
+    DALI_REQUIRE(metric == DALI_METRIC_COSINE || metric == DALI_METRIC_L2SQ, "dali_pairdist_prepared: bad metric %d", metric);
+    DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist_prepared: out must be 16-byte aligned");
+    if (nq == 0 || ng == 0) return DALI_OK;
+    return launch_pairdist((hipStream_t)stream, g_hi, g_lo, g_sq, q_hi, q_lo, q_sq, nq, ng, (d + 31) & ~31, metric,
+                           q_lo != nullptr, out);
+}
+
+extern "C" int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
+                             int metric, int precision, int normalize, float* out) {
+    DALI_REQUIRE(ctx && Q && G && out, "dali_pairdist: null argument");
+    DALI_REQUIRE(nq >= 0 && ng >= 0 && d > 0, "dali_pairdist: bad shape nq=%d ng=%d d=%d", nq, ng, d);
+    DALI_REQUIRE(metric == DALI_METRIC_COSINE || metric == DALI_METRIC_L2SQ, "dali_pairdist: bad metric %d", metric);
+    DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist: bad precision %d", precision);
+    DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist: out must be 16-byte aligned");
+    if (nq == 0 || ng == 0) return DALI_OK;
+    const int Kp = (d + 31) & ~31;
+    const bool split = precision == DALI_PREC_BF16X3;
+    const size_t rows = (size_t)nq + ng;
+    const size_t arr_bytes = align_up(rows * Kp * sizeof(uint16_t), 256);
+    const size_t total = arr_bytes * (split ? 2 : 1) + align_up(rows * sizeof(float), 256);
+    char* ws = static_cast<char*>(workspace(ctx, total));
+    if (!ws) return DALI_ERR_NOMEM;
+    uint16_t* hi = reinterpret_cast<uint16_t*>(ws);
+    uint16_t* lo = split ? reinterpret_cast<uint16_t*>(ws + arr_bytes) : nullptr;
+    float* sq = reinterpret_cast<float*>(ws + arr_bytes * (split ? 2 : 1));
+    uint16_t* qhi = hi + (size_t)ng * Kp;
+    uint16_t* qlo = lo ? lo + (size_t)ng * Kp : nullptr;
+    int rc = dali_pairdist_prepare(ctx, stream, G, ng, d, normalize, hi, lo, sq);       // gallery rows first
+    if (rc != DALI_OK) return rc;
+    rc = dali_pairdist_prepare(ctx, stream, Q, nq, d, normalize, qhi, qlo, sq + ng);
+    if (rc != DALI_OK) return rc;
+    return launch_pairdist((hipStream_t)stream, hi, lo, sq, qhi, qlo, sq + ng, nq, ng, Kp, metric, split, out);
+}
+
+extern "C" int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat, const int32_t* q_pids,
+                              const int32_t* g_pids, const int32_t* q_camids, const int32_t* g_camids, int nq, int ng,
+                              int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid, float* ap,
+                              int32_t* first_rank, int32_t* status) {
+    DALI_REQUIRE(ctx && distmat && q_pids && g_pids && q_camids && g_camids && cmc && mAP && num_valid && status,
+                 "dali_rank_eval: null argument");
+    DALI_REQUIRE(nq > 0 && ng > 0, "dali_rank_eval: bad shape nq=%d ng=%d", nq, ng);
+    DALI_REQUIRE(max_rank > 0 && max_rank <= 1024, "dali_rank_eval: max_rank %d outside 1..1024", max_rank);
+    hipStream_t st = (hipStream_t)stream;
+    float* ap_buf = ap;
+    int32_t* fr_buf = first_rank;
+    if (!ap_buf || !fr_buf) {
+        char* ws = static_cast<char*>(workspace(ctx, align_up((size_t)nq * 4, 256) * 2));
+        if (!ws) return DALI_ERR_NOMEM;
+        if (!ap_buf) ap_buf = reinterpret_cast<float*>(ws);
+        if (!fr_buf) fr_buf = reinterpret_cast<int32_t*>(ws + align_up((size_t)nq * 4, 256));
+    }
+    DALI_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(rank_query_kernel, dim3(nq), dim3(256), 0, st, distmat, q_pids, g_pids, q_camids, g_camids, nq, ng,
+                       ap_buf, fr_buf, status);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rank_reduce_kernel, dim3(1), dim3(256), 0, st, ap_buf, fr_buf, nq, max_rank, cmc, mAP, map64, num_valid);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}

@@ -1,0 +1,112 @@
+"""Python entry points of the evaluation kernels (thin wrappers over the C ABI)."""
+import numpy as np
+import torch
+
+from . import _lib
+
+METRIC_COSINE, METRIC_L2SQ = 0, 1
+PREC_BF16X3, PREC_BF16 = 0, 1
+_PREC = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+_METRIC = {"cosine": METRIC_COSINE, "l2sq": METRIC_L2SQ}
+
+
+def l2norm_rows(x, eps=0.0, return_norms=False):
+    """y = x / (|x| + eps) per row (validateModels.py:41-42 eps=0; train_encodersKIT.py:198 eps=1e-9)."""
+    assert x.dim() == 2
+    y = torch.empty_like(x)
+    norms = torch.empty(x.shape[0], device=x.device, dtype=torch.float32) if return_norms else None
+    _lib.check(_lib.lib().dali_l2norm_rows(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, torch.float32, "x"),
+                                            x.shape[0], x.shape[1], float(eps), _lib.ptr(y), _lib.ptr(norms)),
+               "dali_l2norm_rows")
+    return (y, norms) if return_norms else y
+
+
+def l2norm_rows_bwd(x, dy, eps=0.0):
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().dali_l2norm_rows_bwd(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, torch.float32, "x"),
+                                                _lib.ptr(dy, torch.float32, "dy"), x.shape[0], x.shape[1], float(eps),
+                                                _lib.ptr(dx)), "dali_l2norm_rows_bwd")
+    return dx
+
+
+def pairdist(q, g, metric="cosine", precision="bf16x3", normalize=False, out=None):
+    """distmat[nq,ng] fp32 on the GPU: 1 - q@g.T (validateModels.py:47) or squared L2."""
+    assert q.dim() == 2 and g.dim() == 2 and q.shape[1] == g.shape[1]
+    nq, ng, d = q.shape[0], g.shape[0], q.shape[1]
+    if out is None:
+        out = torch.empty(nq, ng, device=q.device, dtype=torch.float32)
+    if nq == 0 or ng == 0:
+        return out
+    _lib.check(_lib.lib().dali_pairdist(_lib.ctx(q.device), _lib.stream_ptr(), _lib.ptr(q, torch.float32, "q"),
+                                         _lib.ptr(g, torch.float32, "g"), nq, ng, d, _METRIC[metric], _PREC[precision],
+                                         int(bool(normalize)), _lib.ptr(out, torch.float32, "out")), "dali_pairdist")
+    return out
+
+
+class PreparedRows:
+    """bf16 hi/lo operand image of a feature matrix (dali_pairdist_prepare)."""
+
+    def __init__(self, x, normalize=False, precision="bf16x3"):
+        assert x.dim() == 2
+        self.n, self.d = x.shape
+        kp = (self.d + 31) // 32 * 32
+        self.hi = torch.empty(self.n, kp, device=x.device, dtype=torch.int16)
+        self.lo = torch.empty(self.n, kp, device=x.device, dtype=torch.int16) if precision == "bf16x3" else None
+        self.sq = torch.empty(max(self.n, 1), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dali_pairdist_prepare(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, torch.float32, "x"),
+                                                     self.n, self.d, int(bool(normalize)), _lib.ptr(self.hi),
+                                                     _lib.ptr(self.lo), _lib.ptr(self.sq)), "dali_pairdist_prepare")
+
+
+def pairdist_prepared(qp, gp, metric="cosine", out=None):
+    assert qp.d == gp.d and (qp.lo is None) == (gp.lo is None)
+    if out is None:
+        out = torch.empty(qp.n, gp.n, device=qp.hi.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dali_pairdist_prepared(_lib.ctx(out.device), _lib.stream_ptr(), _lib.ptr(qp.hi), _lib.ptr(qp.lo),
+                                                  _lib.ptr(qp.sq), _lib.ptr(gp.hi), _lib.ptr(gp.lo), _lib.ptr(gp.sq),
+                                                  qp.n, gp.n, qp.d, _METRIC[metric], _lib.ptr(out, torch.float32, "out")),
+               "dali_pairdist_prepared")
+    return out
+
+
+def factorize_ids(*arrays):
+    """Shared int32 codes for id columns (the reference carries pids / camids as numpy strings)."""
+    flat = np.concatenate([np.asarray(a).ravel() for a in arrays])
+    _, inv = np.unique(flat, return_inverse=True)
+    out, o = [], 0
+    for a in arrays:
+        n = np.asarray(a).size
+        out.append(inv[o:o + n].astype(np.int32))
+        o += n
+    return out
+
+
+def rank_eval(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, return_per_query=False):
+    """market1501 CMC/mAP of torchreid.metrics.evaluate_rank (validateModels.py:68) on the GPU.
+    distmat: CUDA fp32 [nq,ng].  Returns (cmc numpy float32 [max_rank], mAP float)."""
+    nq, ng = distmat.shape
+    dev = distmat.device
+    max_rank = min(max_rank, ng)
+    qp, gp = factorize_ids(q_pids, g_pids)
+    qc, gc = factorize_ids(q_camids, g_camids)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    qp, gp, qc, gc = t(qp), t(gp), t(qc), t(gc)
+    cmc = torch.empty(max_rank, device=dev, dtype=torch.float32)
+    mAP = torch.empty(1, device=dev, dtype=torch.float32)
+    map64 = torch.empty(1, device=dev, dtype=torch.float64)
+    nvalid = torch.empty(1, device=dev, dtype=torch.int32)
+    status = torch.empty(1, device=dev, dtype=torch.int32)
+    ap = torch.empty(nq, device=dev, dtype=torch.float32)
+    fr = torch.empty(nq, device=dev, dtype=torch.int32)
+    _lib.check(_lib.lib().dali_rank_eval(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(distmat, torch.float32, "distmat"),
+                                          _lib.ptr(qp), _lib.ptr(gp), _lib.ptr(qc), _lib.ptr(gc), nq, ng, max_rank,
+                                          _lib.ptr(cmc), _lib.ptr(mAP), _lib.ptr(map64), _lib.ptr(nvalid), _lib.ptr(ap),
+                                          _lib.ptr(fr), _lib.ptr(status)), "dali_rank_eval")
+    if int(status.item()) != 0:
+        raise _lib.DaliError("dali_rank_eval: a query has more than 4096 matches (documented limit)")
+    if int(nvalid.item()) == 0:
+        raise AssertionError("Error: all query identities do not appear in gallery")
+    res = (cmc.cpu().numpy(), float(map64.item()))
+    if return_per_query:
+        return res + (ap.cpu().numpy(), fr.cpu().numpy())
+    return res

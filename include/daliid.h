@@ -1,0 +1,96 @@
+/* daliid.h -- C ABI of libdaliid_hip.so: the MI355X (gfx950) kernels under the DaliID Person-ReID
+ * hot path (embedding train step + gallery distance / CMC-mAP evaluation).
+ *
+ * The reference (Gabrielcb/DaliID) is pure Python and has NO FFI of its own; its "plugin interface"
+ * for this path is the Python module surface mainKIT.py consumes.  Each entry point
+ * below cites the reference call it stands under (paths relative to Person-ReID/).  The Python mirror
+ * in daliid_amd/ binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (DALI_OK) or a negative dali_status; dali_last_error() gives the
+ *     message of the calling thread's last failure.  Nothing throws across the boundary.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller (PyTorch) owns every
+ *     buffer.  The library only owns the opaque dali_ctx (a grow-only device workspace) and net plans.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, nothing synchronises.
+ *   - bf16 tensors are passed as uint16_t* (raw bits).  Activations are NHWC.
+ */
+#ifndef DALIID_H
+#define DALIID_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DALI_OK = 0,
+    DALI_ERR_INVALID = -1,   /* null pointer, bad shape / alignment / enum */
+    DALI_ERR_HIP = -2,       /* a HIP runtime call failed */
+    DALI_ERR_NOMEM = -3,     /* workspace allocation failed */
+    DALI_ERR_LIMIT = -4,     /* a documented capacity limit was exceeded */
+    DALI_ERR_UNSUPPORTED = -5
+} dali_status;
+
+typedef struct dali_ctx dali_ctx;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int dali_version(void);
+const char* dali_last_error(void);
+/* One context per process / GPU.  `device` is the HIP device ordinal. */
+int dali_ctx_create(int device, dali_ctx** out);
+int dali_ctx_destroy(dali_ctx* ctx);
+/* Pre-size the workspace (hipMalloc happens here, not inside later calls / graph captures). */
+int dali_ctx_reserve(dali_ctx* ctx, size_t bytes);
+
+/* ---- evaluation path: validateModels.validate (validateModels.py:35-58) ------------------------- */
+typedef enum { DALI_METRIC_COSINE = 0,   /* 1 - q.g         validateModels.py:47, evaluate.py:291 */
+               DALI_METRIC_L2SQ = 1      /* |q|^2+|g|^2-2q.g  (square of the commented cdist, :45) */
+} dali_metric;
+typedef enum { DALI_PREC_BF16X3 = 0,     /* split-bf16 (hi*hi+hi*lo+lo*hi), fp32 accumulate: ~1e-6 abs */
+               DALI_PREC_BF16 = 1        /* single bf16 product, fp32 accumulate: ~1e-4 abs on unit rows */
+} dali_precision;
+
+/* y = x / (|x|_2 + eps), rows of an fp32 [n,d] matrix.
+ * validateModels.py:41-42 (eps = 0) and train_encodersKIT.py:198 (eps = 1e-9).
+ * y may alias x.  norms (nullable) receives |x|_2 per row. */
+int dali_l2norm_rows(dali_ctx* ctx, void* stream, const float* x, int n, int d, float eps,
+                     float* y, float* norms);
+/* Backward of the above: dx = dy/(n+eps) - x*(x.dy)/(n*(n+eps)^2); needs the forward INPUT x. */
+int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x, const float* dy, int n, int d,
+                         float eps, float* dx);
+
+/* out[nq,ng] (fp32, row-major) = metric(Q[nq,d], G[ng,d]); fp32 inputs.
+ * normalize != 0 fuses the row normalisation of validateModels.py:41-42 into the operand pre-pass
+ * (the reference sequence normalise -> 1 - q@g.T becomes one call).
+ * Workspace: (nq+ng) * roundup(d,32) * 4 bytes (bf16 hi+lo copies) + (nq+ng)*4. */
+int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
+                  int metric, int precision, int normalize, float* out);
+
+/* The two halves of dali_pairdist, for callers that reuse a prepared gallery against many query sets:
+ * prepare: X[n,d] fp32 -> bf16 hi (and residual lo, nullable => single-bf16 mode) padded to
+ * Kp = roundup(d,32) columns, plus |row|^2 (after the optional normalisation). */
+int dali_pairdist_prepare(dali_ctx* ctx, void* stream, const float* X, int n, int d, int normalize,
+                          uint16_t* hi, uint16_t* lo, float* sq);
+int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const uint16_t* q_hi, const uint16_t* q_lo,
+                           const float* q_sq, const uint16_t* g_hi, const uint16_t* g_lo, const float* g_sq,
+                           int nq, int ng, int d, int metric, float* out);
+
+/* market1501-protocol CMC / mAP: the arithmetic of torchreid.metrics.evaluate_rank(distmat, q_pids,
+ * g_pids, q_camids, g_camids, use_metric_cuhk03=False) called at validateModels.py:68.
+ * ids are int32 codes (the Python mirror factorises the reference's string columns).
+ * Exact distance ties are ordered by ascending gallery index.
+ * Outputs (device): cmc[max_rank] fp32, mAP[1] fp32 (+ fp64 copy in map64[1], nullable),
+ * num_valid[1] int32 (queries with at least one match after junk removal),
+ * per-query ap[nq] fp32 and first_rank[nq] int32 (-1 = invalid query) -- both nullable.
+ * Limit: at most 4096 matches per query (DALI_ERR_LIMIT is reported through status[0]). */
+int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat, const int32_t* q_pids,
+                   const int32_t* g_pids, const int32_t* q_camids, const int32_t* g_camids, int nq, int ng,
+                   int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid,
+                   float* ap, int32_t* first_rank, int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DALIID_H */

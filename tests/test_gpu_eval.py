@@ -1,0 +1,153 @@
+"""GPU parity: evaluation path (l2norm, pair distance on MFMA, market1501 ranking) through the C ABI
+vs the CPU oracle.  Tolerances are stated per precision mode."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import evalrank as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from daliid_amd import ops_eval
+    return ops_eval
+
+
+@pytest.mark.parametrize("n,d,eps", [(1, 7, 0.0), (5, 33, 1e-9), (300, 2048, 0.0), (257, 768, 1e-9)])
+def test_l2norm_rows_fwd_bwd(ops, n, d, eps):
+    g = torch.Generator().manual_seed(n * 131 + d)
+    x = torch.randn(n, d, generator=g) * 3.0
+    dy = torch.randn(n, d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = xr / (torch.norm(xr, dim=1, keepdim=True) + eps)       # train_encodersKIT.py:198 / validateModels.py:41
+    (ref * dy).sum().backward()
+    y, nrm = ops.l2norm_rows(x.cuda(), eps, return_norms=True)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(nrm.cpu().numpy(), x.norm(dim=1).numpy(), rtol=2e-6)
+    dx = ops.l2norm_rows_bwd(x.cuda(), dy.cuda(), eps)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("nq,ng,d", [(1, 5, 32), (130, 259, 96), (3, 1031, 64), (129, 128, 160)])
+def test_pairdist_exact_on_small_integers(ops, prec, nq, ng, d):
+    """Small integers are exact in bf16 and their dot products exact in fp32: the MFMA fragment layout,
+    the LDS swizzle, the XCD tile map and every edge tile must reproduce the oracle BIT-EXACTLY."""
+    g = torch.Generator().manual_seed(nq + 7 * ng + d)
+    q = torch.randint(-3, 4, (nq, d), generator=g).float()
+    gal = torch.randint(-3, 4, (ng, d), generator=g).float()
+    gal[:, 0] += torch.arange(ng).float() % 5            # asymmetric, row-dependent
+    q[:, 1] -= torch.arange(nq).float() % 3
+    for metric, ref in (("cosine", E.cosine_distmat(q, gal)), ("l2sq", E.l2sq_distmat(q, gal))):
+        out = ops.pairdist(q.cuda(), gal.cuda(), metric=metric, precision=prec)
+        assert torch.equal(out.cpu(), ref), (metric, (out.cpu() - ref).abs().max())
+
+
+# Tolerances on unit rows (|q.g| <= 1).  bf16: each operand carries <= 2^-9 relative rounding, so
+# |err| <= ~2^-8 * sum|q_i||g_i| <= 3.9e-3 (Cauchy-Schwarz); observed max 1.8e-3.  bf16x3 keeps hi+lo (16 mantissa
+# bits) and drops only lo*lo: worst case ~2e-5, observed max 3.5e-6 at d=33 (few, large components) and < 1e-6 at
+# d >= 768; the fp32 oracle itself carries ~1e-7 * sqrt(d) of its own.
+@pytest.mark.parametrize("prec,atol", [("bf16x3", None), ("bf16", 4e-3)])
+@pytest.mark.parametrize("nq,ng,d", [(64, 200, 33), (257, 1031, 2048), (500, 700, 768)])
+def test_pairdist_matches_oracle(ops, prec, atol, nq, ng, d):
+    if atol is None:
+        atol = 8e-6 if d < 128 else 2e-6
+    g = torch.Generator().manual_seed(d)
+    q = torch.randn(nq, d, generator=g)
+    gal = torch.randn(ng, d, generator=g)
+    # fused normalise + 1 - q.g == validateModels.py:41-47
+    ref = E.validate_features(q, gal)
+    out = ops.pairdist(q.cuda(), gal.cuda(), precision=prec, normalize=True).cpu()
+    assert (out - ref).abs().max().item() <= atol
+    # unnormalised L2^2 (values O(d)): relative tolerance
+    ref2 = E.l2sq_distmat(q, gal)
+    out2 = ops.pairdist(q.cuda(), gal.cuda(), metric="l2sq", precision=prec).cpu()
+    rel = ((out2 - ref2).abs() / ref2.abs().clamp(min=1.0)).max().item()
+    assert rel <= (8e-6 if prec == "bf16x3" else 8e-3)
+
+
+def test_pairdist_prepared_equals_one_shot(ops):
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(100, 256, generator=g).cuda()
+    gal = torch.randn(333, 256, generator=g).cuda()
+    a = ops.pairdist(q, gal, normalize=True)
+    b = ops.pairdist_prepared(ops.PreparedRows(q, True), ops.PreparedRows(gal, True))
+    assert torch.equal(a, b)
+
+
+def test_pairdist_empty(ops):
+    q = torch.zeros(0, 64).cuda()
+    gal = torch.randn(10, 64).cuda()
+    assert ops.pairdist(q, gal).shape == (0, 10)
+
+
+def _rank_case(seed, nq, ng, n_ids, n_cams, ties=False):
+    rng = np.random.default_rng(seed)
+    dist = rng.random((nq, ng)).astype(np.float32)
+    if ties:
+        dist = np.round(dist * 8) / 8          # many exact ties -> exercises the index tie-break
+    return dist, rng.integers(0, n_ids, nq), rng.integers(0, n_ids, ng), rng.integers(0, n_cams, nq), rng.integers(0, n_cams, ng)
+
+
+@pytest.mark.parametrize("seed,nq,ng,n_ids,n_cams,ties", [(0, 17, 61, 6, 3, False), (1, 40, 1000, 12, 2, True),
+                                                          (2, 9, 5000, 3, 4, False), (3, 5, 300, 400, 2, False)])
+def test_rank_eval_matches_oracle_on_same_distmat(ops, seed, nq, ng, n_ids, n_cams, ties):
+    dist, qp, gp, qc, gc = _rank_case(seed, nq, ng, n_ids, n_cams, ties)
+    if seed == 3:
+        qp[0] = gp[0]; qc[0] = gc[0] + 1       # guarantee at least one valid query among many invalid ones
+    ref_cmc, ref_map = E.eval_market1501(dist, qp, gp, qc, gc, max_rank=50)
+    cmc, mAP = ops.rank_eval(torch.from_numpy(dist).cuda(), qp, gp, qc, gc, max_rank=50)
+    np.testing.assert_allclose(cmc, ref_cmc, atol=1e-6)
+    assert abs(mAP - ref_map) < 1e-6
+
+
+def test_rank_eval_string_ids_and_known_answer(ops):
+    g_pids = np.array(["a", "b", "a", "c"]); g_cams = np.array(["0", "0", "1", "0"])
+    dist = torch.tensor([[0.9, 0.1, 0.5, 0.3], [0.2, 0.8, 0.1, 0.4], [0.1, 0.2, 0.3, 0.4]])
+    cmc, mAP = ops.rank_eval(dist.cuda(), np.array(["a", "b", "z"]), g_pids, np.array(["0", "1", "5"]), g_cams, max_rank=4)
+    np.testing.assert_allclose(cmc, [0.0, 0.0, 0.5, 1.0])
+    assert abs(mAP - (1 / 3 + 1 / 4) / 2) < 1e-7
+
+
+def test_validate_pipeline_map_within_1e3(ops):
+    """normalise -> distmat -> CMC/mAP end to end on synthetic ids (north star: mAP within 1e-3)."""
+    q, g, qp, gp, qc, gc = E.synthetic_reid_set(60, 20, 3, 64, noise=3.0, seed=12)
+    ref_d = E.validate_features(q, g)
+    ref_cmc, ref_map = E.eval_market1501(ref_d.numpy(), qp, gp, qc, gc)
+    assert 0.2 < ref_map < 0.999          # a non-trivial ranking problem
+    for prec, tol in (("bf16x3", 2e-5), ("bf16", 1e-3)):
+        d = ops.pairdist(q.cuda(), g.cuda(), precision=prec, normalize=True)
+        cmc, mAP = ops.rank_eval(d, qp, gp, qc, gc)
+        assert abs(mAP - ref_map) < tol, (prec, mAP, ref_map)
+        np.testing.assert_allclose(cmc, ref_cmc, atol=(1.0 / len(qp) + 1e-6) if prec == "bf16" else 2e-5)
+
+
+def test_config5_full_size_properties(ops):
+    """BASELINE config 5 (10k x 100k x 2048): size-independent checks.
+    (a) sampled entries vs fp64 dot products; (b) linearity: sum_g out[q,g] = ng - q . sum_g g;
+    (c) role symmetry: D(Q,G)[i,j] == D(G,Q)[j,i] on a sampled block."""
+    nq, ng, d = 10000, 100000, 2048
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    q = torch.randn(nq, d, device="cuda", generator=gen)
+    g = torch.randn(ng, d, device="cuda", generator=gen)
+    out = ops.pairdist(q, g, precision="bf16x3", normalize=True)
+    qn = (q / q.norm(dim=1, keepdim=True)).double()
+    gn = (g / g.norm(dim=1, keepdim=True)).double()
+    idx_q = torch.randint(0, nq, (4096,), device="cuda", generator=gen)
+    idx_g = torch.randint(0, ng, (4096,), device="cuda", generator=gen)
+    ref = 1.0 - (qn[idx_q] * gn[idx_g]).sum(1)
+    assert (out[idx_q, idx_g].double() - ref).abs().max().item() < 2e-6
+    rows = idx_q[:64]
+    lin = ng - qn[rows] @ gn.sum(0)
+    assert (out[rows].double().sum(1) - lin).abs().max().item() < 1e-2   # 1e5 terms of ~1.0 +- 1e-7
+    sub_q, sub_g = q[:300], g[5000:5600]
+    a = ops.pairdist(sub_q, sub_g, normalize=True)
+    b = ops.pairdist(sub_g, sub_q, normalize=True)
+    assert (a - b.T).abs().max().item() < 1e-6
+    assert (out[:300, 5000:5600] - a).abs().max().item() == 0.0           # tile position does not change values
+    del out
+    torch.cuda.empty_cache()
