@@ -34,6 +34,10 @@ _SIGNATURES = {
                                c_int, c_int, c_void_p],
     "dali_rank_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "dali_conv2d_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p],
+    "dali_conv2d_stat_tiles": [c_int, c_int, c_int, c_int],
+    "dali_conv2d_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9,
+    "dali_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_int],
 }
 _RESTYPES = {"dali_last_error": ctypes.c_char_p}
 

@@ -1,0 +1,519 @@
+// conv.hip -- implicit-GEMM convolutions on bf16 MFMA for the ResNet-50-ReID trunk
+// (Encoders.py:330-339: conv1 7x7/2, bottleneck 1x1 / 3x3 convs, 1x1 downsamples; layer4 at stride 1).
+//
+// One kernel (igemm_conv_kernel) serves forward and data-gradient, one (igemm_wgrad_kernel) the weight
+// gradient.  Activations are NHWC bf16, weights [Cout][R][S][Cin] bf16 (K-contiguous), accumulation fp32.
+//
+//   forward : O[p][co]  = sum_{r,s,ci} W[co][r][s][ci] * X[n, ho*st-pad+r, wo*st-pad+s, ci]
+//   dgrad   : dX[p][ci] = sum_{r,s,co} Wt[ci][r][s][co] * dY[n, (h+pad-r)/st, (w+pad-s)/st, co]   (exact multiples only)
+//   wgrad   : dW[co][r][s][ci] = sum_p dY[p][co] * X[n, ho*st-pad+r, wo*st-pad+s, ci]
+//
+// Fusions: (a) the gathered operand can be transformed on load by a per-channel affine + ReLU
+// (the previous BatchNorm+ReLU is never materialised); (b) the forward epilogue accumulates the
+// per-channel sum / sum-of-squares partials training-mode BatchNorm needs (deterministic, no atomics);
+// (c) the dgrad epilogue can add a residual gradient.
+#include "gemm_tile.h"
+
+namespace dali {
+
+struct GatherGeom {
+    int Hout, Wout;            // pixel grid the GEMM N dimension enumerates (n, ho, wo)
+    int Hin, Win;              // grid of the gathered tensor (bounds)
+    int Ck;                    // channels per tap of the gathered tensor (multiple of 32)
+    int R, S, stride, pad;
+    int mode;                  // 0: hi = ho*stride - pad + r ; 1 (dgrad): hi = (ho + pad - r) / stride if divisible
+    long long img_pitch;       // elements between images of the gathered tensor
+    int row_pitch, pix_pitch;  // elements between rows / pixels
+    int lw, lhw;               // log2(Wout), log2(Hout*Wout) or -1
+};
+
+__device__ __forceinline__ void decode_pixel(const GatherGeom& g, int p, int& n, int& ho, int& wo) {
+    if (g.lhw >= 0 && g.lw >= 0) {
+        n = p >> g.lhw;
+        const int rem = p & ((1 << g.lhw) - 1);
+        ho = rem >> g.lw;
+        wo = rem & ((1 << g.lw) - 1);
+    } else {
+        const int hw = g.Hout * g.Wout;
+        n = p / hw;
+        const int rem = p - n * hw;
+        ho = rem / g.Wout;
+        wo = rem - ho * g.Wout;
+    }
+}
+
+// offset (elements) of tap (r,s) for base coords, or -1 if the tap falls outside / is not hit
+__device__ __forceinline__ long long tap_offset(const GatherGeom& g, long long img_base, int h0, int w0, int r, int s) {
+    int hi, wi;
+    if (g.mode == 0) {
+        hi = h0 + r;
+        wi = w0 + s;
+    } else {
+        const int th = h0 - r, tw = w0 - s;
+        if (th < 0 || tw < 0) return -1;
+        if (g.stride == 2) {
+            if ((th | tw) & 1) return -1;
+            hi = th >> 1; wi = tw >> 1;
+        } else {
+            hi = th; wi = tw;
+        }
+    }
+    if (hi < 0 || hi >= g.Hin || wi < 0 || wi >= g.Win) return -1;
+    return img_base + (long long)hi * g.row_pitch + (long long)wi * g.pix_pitch;
+}
+
+__device__ __forceinline__ uint4 bn_relu_chunk(uint4 v, const float* __restrict__ sc, const float* __restrict__ sh, int relu) {
+    const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(sh), b1 = *reinterpret_cast<const float4*>(sh + 4);
+    const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float lo = bf16_bits_to_f32(w[t] & 0xffffu) * s[2 * t] + b[2 * t];
+        float hi = bf16_bits_to_f32(w[t] >> 16) * s[2 * t + 1] + b[2 * t + 1];
+        if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+        o[t] = pack_bf16x2(lo, hi);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad
+// ------------------------------------------------------------------------------------------------
+struct IGemmArgs {
+    const uint16_t* W;        // [Cm][R*S*Ck]
+    const uint16_t* X;        // gathered tensor
+    uint16_t* O;              // [P][Cm]
+    const uint16_t* Res;      // optional residual [P][Cm], added in the epilogue
+    const float* in_scale;    // optional [Ck] affine (+ReLU) applied to X on load
+    const float* in_shift;
+    float* stats;             // optional [tiles_n][Cm][2] partial sum / sumsq of the fp32 results
+    int Cm, P, in_relu;
+    GatherGeom g;
+};
+
+template <int TN, bool IN_BN>
+struct PixelLoader {
+    static constexpr int BCH = TN * 4 / 256;
+    const uint16_t* X;
+    const float* sc; const float* sh;
+    GatherGeom g;
+    int relu;
+    long long img_base[BCH];
+    int h0[BCH], w0[BCH];
+    bool ok[BCH];
+    int kc;                   // this thread's 16-byte chunk inside the 32-channel k-tile
+    int tiles_per_tap;
+
+    __device__ __forceinline__ void init(const IGemmArgs& a, int p0) {
+        X = a.X; sc = a.in_scale; sh = a.in_shift; g = a.g; relu = a.in_relu;
+        kc = threadIdx.x & 3;
+        tiles_per_tap = g.Ck >> 5;
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int row = (threadIdx.x + i * 256) >> 2;
+            const int p = p0 + row;
+            ok[i] = p < a.P;
+            int n = 0, ho = 0, wo = 0;
+            if (ok[i]) decode_pixel(g, p, n, ho, wo);
+            img_base[i] = (long long)n * g.img_pitch;
+            if (g.mode == 0) { h0[i] = ho * g.stride - g.pad; w0[i] = wo * g.stride - g.pad; }
+            else { h0[i] = ho + g.pad; w0[i] = wo + g.pad; }
+        }
+    }
+    // row index is implied by (tid, i): the mainloop calls with row == (tid + i*256) >> 2
+    __device__ __forceinline__ uint4 operator()(int /*arr*/, int row, int kt, int /*kc*/) const {
+        const int i = row >> 6;                    // rows handled by this thread are 64 apart
+        const int tap = kt / tiles_per_tap;
+        const int c0 = (kt - tap * tiles_per_tap) * 32 + kc * 8;
+        const int r = tap / g.S, s = tap - r * g.S;
+        // BCH is small: select this thread's i-th row by unrolled compare (keeps arrays in registers)
+        long long off = -1;
+#pragma unroll
+        for (int t = 0; t < BCH; ++t)
+            if (t == i && ok[t]) off = tap_offset(g, img_base[t], h0[t], w0[t], r, s);
+        if (off < 0) return make_uint4(0, 0, 0, 0);
+        uint4 v = *reinterpret_cast<const uint4*>(X + off + c0);
+        if constexpr (IN_BN) v = bn_relu_chunk(v, sc + c0, sh + c0, relu);
+        return v;
+    }
+};
+
+struct WeightLoader {
+    const uint16_t* W; int m0, Cm, K;
+    __device__ __forceinline__ uint4 operator()(int /*arr*/, int row, int kt, int kc) const {
+        const int m = m0 + row;
+        if (m >= Cm) return make_uint4(0, 0, 0, 0);
+        return *reinterpret_cast<const uint4*>(W + (size_t)m * K + kt * 32 + kc * 8);
+    }
+};
+
+template <int TM, int TN, bool IN_BN>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+    using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    f32x4_t acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int K = a.g.R * a.g.S * a.g.Ck;
+    WeightLoader la{a.W, tm * TM, a.Cm, K};
+    PixelLoader<TN, IN_BN> lb;
+    lb.init(a, tn * TN);
+    gemm_mainloop<Cfg>(acc, la, lb, K >> 5, smem);
+
+    int mb, nb;
+    acc_coords<Cfg>(mb, nb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- store O (+ residual) ----
+#pragma unroll
+    for (int j = 0; j < Cfg::FN; ++j) {
+        const int p = tn * TN + nb + j * 16;
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i) {
+            const int c = tm * TM + mb + i * 16;
+            if (p < a.P && c < a.Cm) {      // Cm is a multiple of 4: the 4 channels are all valid
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const size_t o = (size_t)p * a.Cm + c;
+                if (a.Res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.Res + o);
+                    v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
+                    v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                }
+                *reinterpret_cast<uint2*>(a.O + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+    }
+    // ---- BatchNorm partial statistics: per channel sum / sumsq over this tile's pixels ----
+    if (a.stats) {
+        __syncthreads();                           // mainloop LDS reads are done: reuse smem
+        float* red = reinterpret_cast<float*>(smem);   // [2 (wn)][TM][2]
+        const int wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i) {
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < Cfg::FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s1[r] += v; s2[r] += v * v; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+            }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ml = mb + i * 16 + r;          // channel inside the tile
+                    red[(wn * TM + ml) * 2 + 0] = s1[r];
+                    red[(wn * TM + ml) * 2 + 1] = s2[r];
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < TM; t += 256) {
+            const int c = tm * TM + t;
+            if (c < a.Cm) {
+                float* dst = a.stats + ((size_t)tn * a.Cm + c) * 2;
+                dst[0] = red[t * 2] + red[(TM + t) * 2];
+                dst[1] = red[t * 2 + 1] + red[(TM + t) * 2 + 1];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: M = Cm (channels of dY), N = R*S*Ck, K = pixels.  Both operands are stored pixel-major, so the
+// MFMA fragments (8 consecutive k per lane) are produced by ds_read_b64_tr_b16 transposing reads.
+// LDS image per operand and stage: [32 pixels][128 channels] bf16 (256-byte rows); the 32-byte chunk index is
+// XORed with swz(row) = (row&3) | ((row>>3)&1)<<2 so that the 8 rows one 32-lane half touches per read
+// ({k0..k0+3} and {k0+8..k0+11}) fall on 8 distinct 32-byte bank groups of the 256-byte bank row.
+// Split-K over pixels: block (tile, ks) writes an fp32 slab; a second kernel sums the slabs in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct WGradArgs {
+    const uint16_t* dY;       // [P][Cm]
+    const uint16_t* X;        // gathered tensor
+    float* partial;           // [splits][Cm][Ntot]
+    const float* in_scale; const float* in_shift;
+    int Cm, P, Ntot, in_relu;
+    int splits, pix_per_split;    // pix_per_split multiple of 32
+    GatherGeom g;
+};
+
+__device__ __forceinline__ int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8_t tr_frag(const uint16_t* tile, int chunk32, int lane) {
+    // rows 8g+q (first read) and 8g+4+q (second read), g = lane>>4, q = (lane&15)>>2, columns 4*(lane&3)..+3
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row0 = 8 * g + q, row1 = row0 + 4;
+    const int off0 = row0 * 128 + ((chunk32 ^ wg_swz(row0)) << 4) + 4 * p;      // in bf16 elements
+    const int off1 = row1 * 128 + ((chunk32 ^ wg_swz(row1)) << 4) + 4 * p;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + off0));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + off1));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <bool IN_BN>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+    constexpr int TILE = 32 * 128;                       // elements per operand per stage
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 2 * TILE];   // 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = tiles_m * tiles_n;
+    const int tile = blockIdx.x % tiles, ks = blockIdx.x / tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const GatherGeom g = a.g;
+
+    // this thread's fixed 16-byte column chunk (same for both of its rows): 16 chunks per 128-wide row
+    const int c16 = tid & 15;
+    const int am = m0 + c16 * 8;                         // dY channel of the chunk
+    const bool a_ok = am < a.Cm;
+    const int bn = n0 + c16 * 8;                         // column in [0, Ntot): tap*Ck + ci
+    const bool b_ok = bn < a.Ntot;
+    const int tap = b_ok ? bn / g.Ck : 0;
+    const int ci = bn - tap * g.Ck;
+    const int r = tap / g.S, s = tap - r * g.S;
+
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.P, p_begin + a.pix_per_split);
+    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+
+    uint4 ra[2], rb[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 4) + i * 16;
+            const int p = p_begin + kt * 32 + row;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (p < p_end) {
+                if (a_ok) ra[i] = *reinterpret_cast<const uint4*>(a.dY + (size_t)p * a.Cm + am);
+                if (b_ok) {
+                    int n, ho, wo;
+                    decode_pixel(g, p, n, ho, wo);
+                    const long long off = tap_offset(g, (long long)n * g.img_pitch, ho * g.stride - g.pad, wo * g.stride - g.pad, r, s);
+                    if (off >= 0) {
+                        uint4 v = *reinterpret_cast<const uint4*>(a.X + off + ci);
+                        if constexpr (IN_BN) v = bn_relu_chunk(v, a.in_scale + ci, a.in_shift + ci, a.in_relu);
+                        rb[i] = v;
+                    }
+                }
+            }
+        }
+    };
+    auto sstore = [&](int stage) {
+        uint16_t* sa = smem + stage * 2 * TILE;
+        uint16_t* sb = sa + TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 4) + i * 16;
+            const int off = row * 128 + (((c16 >> 1) ^ wg_swz(row)) << 4) + (c16 & 1) * 8;
+            *reinterpret_cast<uint4*>(sa + off) = ra[i];
+            *reinterpret_cast<uint4*>(sb + off) = rb[i];
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (ksteps > 0) {
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < ksteps; ++kt) {
+            const bool more = (kt + 1) < ksteps;
+            if (more) gload(kt + 1);
+            const uint16_t* sa = smem + (kt & 1) * 2 * TILE;
+            const uint16_t* sb = sa + TILE;
+            bf16x8_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, wm * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t fb = tr_frag(sb, wn * 4 + j, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+            }
+            if (more) sstore((kt + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // epilogue: fp32 slab
+    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
+                if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
+            }
+        }
+}
+
+// out[e] (= or +=) sum_s partial[s][e]; fixed order => deterministic.  HBM-bound.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            size_t elems, int splits, int accumulate) {
+    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= elems) return;
+    if (i4 + 3 < elems) {
+        float4 s = *reinterpret_cast<const float4*>(partial + i4);
+        for (int k = 1; k < splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * elems + i4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(out + i4); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        *reinterpret_cast<float4*>(out + i4) = s;
+    } else {
+        for (size_t e = i4; e < elems; ++e) {
+            float s = partial[e];
+            for (int k = 1; k < splits; ++k) s += partial[(size_t)k * elems + e];
+            out[e] = accumulate ? out[e] + s : s;
+        }
+    }
+}
+
+static inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace dali
+
+using namespace dali;
+
+namespace dali {
+
+// Host-side launchers shared with the net plan (resnet_plan.hip).
+int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
+    const bool in_bn = a.in_scale != nullptr;
+    const bool narrow = a.Cm <= 64;
+    IGemmArgs args = a;
+    args.g.lw = ilog2_exact(a.g.Wout);
+    args.g.lhw = ilog2_exact(a.g.Hout * a.g.Wout);
+    if (narrow) {
+        using Cfg = GemmCfg<64, 256, 1, 1, 1>;
+        const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
+        const int grid = xcd_tile_grid(tiles_m, tiles_n);
+        if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<64, 256, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_kernel<64, 256, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+    } else {
+        using Cfg = GemmCfg<128, 128, 1, 1, 1>;
+        const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
+        const int grid = xcd_tile_grid(tiles_m, tiles_n);
+        if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<128, 128, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+    }
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int igemm_conv_stat_tiles(int Cm, int P) { return Cm <= 64 ? (P + 255) / 256 : (P + 127) / 128; }
+
+// Chooses the split count so that the grid has ~target blocks; returns slab bytes through *ws_bytes.
+void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes) {
+    const int tiles = ((Cm + 127) / 128) * ((Ntot + 127) / 128);
+    int sp = (target_blocks + tiles - 1) / tiles;
+    const int max_sp = (P + 255) / 256;              // at least 8 k-steps per block
+    if (sp > max_sp) sp = max_sp;
+    if (sp < 1) sp = 1;
+    int pps = ((P + sp - 1) / sp + 31) & ~31;
+    sp = (P + pps - 1) / pps;
+    *splits = sp; *pix_per_split = pps;
+    *ws_bytes = (size_t)sp * Cm * Ntot * sizeof(float);
+}
+
+int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate) {
+    WGradArgs args = a;
+    args.g.lw = ilog2_exact(a.g.Wout);
+    args.g.lhw = ilog2_exact(a.g.Hout * a.g.Wout);
+    const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.Ntot + 127) / 128;
+    const int grid = tiles_m * tiles_n * a.splits;
+    if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
+    DALI_LAUNCH_CHECK();
+    const size_t elems = (size_t)a.Cm * a.Ntot;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256 + 1)), dim3(256), 0, st, a.partial, out, elems,
+                       a.splits, accumulate);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+}  // namespace dali
+
+static int fill_geom(GatherGeom& g, int n_img, int Hin, int Win, int Ck, int Hout, int Wout, int R, int S, int stride, int pad, int mode) {
+    g.Hout = Hout; g.Wout = Wout; g.Hin = Hin; g.Win = Win; g.Ck = Ck; g.R = R; g.S = S; g.stride = stride; g.pad = pad;
+    g.mode = mode;
+    g.pix_pitch = Ck; g.row_pitch = Win * Ck; g.img_pitch = (long long)Hin * Win * Ck;
+    g.lw = g.lhw = -1;
+    (void)n_img;
+    return 0;
+}
+
+// ---- single-op C ABI (used by the parity tests; the net plan calls the launchers directly) ----------------
+extern "C" int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y,
+                               int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
+                               const float* in_scale, const float* in_shift, int in_relu, float* stats) {
+    DALI_REQUIRE(ctx && x && w && y, "dali_conv2d_fwd: null argument");
+    DALI_REQUIRE(cin % 32 == 0 && cout % 4 == 0, "dali_conv2d_fwd: cin must be a multiple of 32 and cout of 4 (cin=%d cout=%d)", cin, cout);
+    DALI_REQUIRE(stride == 1 || stride == 2, "dali_conv2d_fwd: stride %d unsupported", stride);
+    DALI_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dali_conv2d_fwd: in_scale/in_shift must come together");
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    IGemmArgs a{};
+    a.W = w; a.X = x; a.O = y; a.Res = nullptr; a.in_scale = in_scale; a.in_shift = in_shift; a.stats = stats;
+    a.Cm = cout; a.P = n * ho * wo; a.in_relu = in_relu;
+    fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
+    return launch_igemm_conv((hipStream_t)stream, a);
+}
+
+extern "C" int dali_conv2d_stat_tiles(int cout, int n, int ho, int wo) { return igemm_conv_stat_tiles(cout, n * ho * wo); }
+
+extern "C" int dali_conv2d_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, uint16_t* dx,
+                                 const uint16_t* residual, int n, int h, int wd, int cin, int cout, int r, int s,
+                                 int stride, int pad) {
+    DALI_REQUIRE(ctx && dy && wt && dx, "dali_conv2d_dgrad: null argument");
+    DALI_REQUIRE(cout % 32 == 0 && cin % 4 == 0, "dali_conv2d_dgrad: cout must be a multiple of 32 and cin of 4 (cin=%d cout=%d)", cin, cout);
+    DALI_REQUIRE(stride == 1 || stride == 2, "dali_conv2d_dgrad: stride %d unsupported", stride);
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    IGemmArgs a{};
+    a.W = wt; a.X = dy; a.O = dx; a.Res = residual; a.in_scale = nullptr; a.in_shift = nullptr; a.stats = nullptr;
+    a.Cm = cin; a.P = n * h * wd; a.in_relu = 0;
+    fill_geom(a.g, n, ho, wo, cout, h, wd, r, s, stride, pad, 1);
+    return launch_igemm_conv((hipStream_t)stream, a);
+}
+
+extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* dy, float* dw,
+                                 int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
+                                 const float* in_scale, const float* in_shift, int in_relu, int accumulate) {
+    DALI_REQUIRE(ctx && x && dy && dw, "dali_conv2d_wgrad: null argument");
+    DALI_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "dali_conv2d_wgrad: cin and cout must be multiples of 8 (cin=%d cout=%d)", cin, cout);
+    DALI_REQUIRE(stride == 1 || stride == 2, "dali_conv2d_wgrad: stride %d unsupported", stride);
+    DALI_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dali_conv2d_wgrad: in_scale/in_shift must come together");
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    WGradArgs a{};
+    a.dY = dy; a.X = x; a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+    a.Cm = cout; a.P = n * ho * wo; a.Ntot = r * s * cin;
+    fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
+    size_t ws_bytes;
+    wgrad_plan(a.Cm, a.Ntot, a.P, 1024, &a.splits, &a.pix_per_split, &ws_bytes);
+    a.partial = static_cast<float*>(workspace(ctx, ws_bytes));
+    if (!a.partial) return DALI_ERR_NOMEM;
+    return launch_igemm_wgrad((hipStream_t)stream, a, dw, accumulate);
+}

@@ -90,6 +90,31 @@ int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat, const int3
                    int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid,
                    float* ap, int32_t* first_rank, int32_t* status);
 
+/* ---- training path: Encoders.ResNet50ReID trunk (Encoders.py:330-339) ----------------------------- *
+ * Single-op entry points (the parity tests call these; the net plan below chains the same kernels).
+ * Layouts: activations NHWC bf16; forward weights [cout][r][s][cin] bf16; dgrad weights
+ * [cin][r][s][cout] bf16; weight gradients [cout][r][s][cin] fp32.  stride in {1,2}.
+ * These stand under torch.nn.Conv2d forward/backward of torchvision's resnet50 as wrapped by
+ * Encoders.py:312-322. */
+
+/* y[n,ho,wo,cout] = conv(x).  If in_scale/in_shift (fp32 [cin]) are given, x is read as
+ * relu?(x*in_scale+in_shift) (the preceding BatchNorm(+ReLU) fused into the operand load; padding stays 0).
+ * stats (nullable): fp32 [dali_conv2d_stat_tiles(...)][cout][2] per-tile partial (sum, sum of squares) of the
+ * fp32 results -- the batch statistics training-mode BatchNorm needs.  cin % 32 == 0, cout % 4 == 0. */
+int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y,
+                    int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
+                    const float* in_scale, const float* in_shift, int in_relu, float* stats);
+int dali_conv2d_stat_tiles(int cout, int n, int ho, int wo);
+/* dx[n,h,w,cin] = conv_transpose(dy, w) (+ residual[n,h,w,cin] if given).  cout % 32 == 0, cin % 4 == 0. */
+int dali_conv2d_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, uint16_t* dx,
+                      const uint16_t* residual, int n, int h, int wd, int cin, int cout, int r, int s,
+                      int stride, int pad);
+/* dw[cout][r][s][cin] (fp32) = (accumulate ? dw : 0) + sum_p dy[p][cout] * x_gathered[p][r,s,cin]; x may carry
+ * the same fused affine(+ReLU) as the forward.  Deterministic split-K (fixed-order slab reduction). */
+int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* dy, float* dw,
+                      int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
+                      const float* in_scale, const float* in_shift, int in_relu, int accumulate);
+
 #ifdef __cplusplus
 }
 #endif

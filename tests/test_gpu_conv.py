@@ -1,0 +1,103 @@
+"""GPU parity: implicit-GEMM convolution kernels (forward, data gradient, weight gradient) vs torch CPU fp32.
+
+Small-integer operands are exact in bf16 and their products/sums exact in fp32, so forward/dgrad must equal the
+fp32 oracle rounded once to bf16 BIT-EXACTLY and wgrad (fp32 out) must equal it exactly.  Random-data cases use a
+1-bf16-ulp tolerance (accumulation order differs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+bf16 = torch.bfloat16
+
+# (n, h, w, cin, cout, r, s, stride, pad)
+CASES = [
+    (2, 8, 4, 64, 256, 1, 1, 1, 0),
+    (3, 8, 8, 256, 64, 1, 1, 1, 0),       # narrow-M tile (64 x 256)
+    (2, 8, 8, 64, 128, 1, 1, 2, 0),       # 1x1 stride-2 downsample
+    (2, 9, 5, 32, 64, 3, 3, 1, 1),        # non power-of-two pixel grid
+    (1, 16, 8, 128, 128, 3, 3, 1, 1),
+    (2, 8, 8, 64, 96, 3, 3, 2, 1),        # 3x3 stride 2
+    (5, 7, 3, 96, 160, 3, 3, 1, 1),       # ragged everything
+    (4, 16, 8, 512, 512, 3, 3, 1, 1),     # layer4 conv2 shape (small batch)
+]
+
+
+@pytest.fixture(scope="module")
+def nn():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from daliid_amd import ops_nn
+    return ops_nn
+
+
+def _ints(shape, gen, lo=-2, hi=3, density=1.0):
+    t = torch.randint(lo, hi, shape, generator=gen).float()
+    if density < 1.0:
+        t = t * (torch.rand(shape, generator=gen) < density).float()
+    return t
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad_exact_integers(nn, case):
+    n, h, w, cin, cout, r, s, stride, pad = case
+    gen = torch.Generator().manual_seed(sum(case) * 7 + cin)
+    x = _ints((n, cin, h, w), gen).requires_grad_(True)
+    wt = _ints((cout, cin, r, s), gen, density=0.5).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=stride, padding=pad)
+    dy = _ints(tuple(y.shape), gen, density=0.5)
+    y.backward(dy)
+    xg = nhwc(x.detach()).to(bf16).cuda()
+    w_fwd = wt.detach().permute(0, 2, 3, 1).contiguous().to(bf16).cuda()           # [cout][r][s][cin]
+    w_dg = wt.detach().permute(1, 2, 3, 0).contiguous().to(bf16).cuda()            # [cin][r][s][cout]
+    dyg = nhwc(dy).to(bf16).cuda()
+    # forward (+ batch statistics)
+    yk, stats = nn.conv2d_fwd(xg, w_fwd, stride, pad, want_stats=True)
+    ref_y = nhwc(y.detach())
+    assert torch.equal(yk.cpu(), ref_y.to(bf16)), (yk.cpu().float() - ref_y).abs().max()
+    st = stats.double().sum(0).cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), ref_y.double().sum((0, 1, 2)).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(st[:, 1].numpy(), (ref_y.double() ** 2).sum((0, 1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    # data gradient (+ residual)
+    if cout % 32 == 0:
+        dxk = nn.conv2d_dgrad(dyg, w_dg, (h, w), stride, pad)
+        ref_dx = nhwc(x.grad)
+        assert torch.equal(dxk.cpu(), ref_dx.to(bf16)), (dxk.cpu().float() - ref_dx).abs().max()
+        res = _ints((n, h, w, cin), gen)
+        dxr = nn.conv2d_dgrad(dyg, w_dg, (h, w), stride, pad, residual=res.to(bf16).cuda())
+        assert torch.equal(dxr.cpu(), (ref_dx + res).to(bf16))
+    # weight gradient (fp32, exact)
+    dwk = nn.conv2d_wgrad(xg, dyg, (r, s), stride, pad)
+    ref_dw = wt.grad.permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(dwk.cpu(), ref_dw), (dwk.cpu() - ref_dw).abs().max()
+    acc = nn.conv2d_wgrad(xg, dyg, (r, s), stride, pad, out=dwk.clone(), accumulate=True)
+    assert torch.equal(acc.cpu(), 2 * ref_dw)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5], CASES[7]])
+def test_conv_fused_bn_relu_operand(nn, case):
+    """Operand transform relu(x*scale+shift) fused into the load (forward and wgrad), random data."""
+    n, h, w, cin, cout, r, s, stride, pad = case
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(n, h, w, cin, generator=gen).to(bf16)
+    scale = torch.rand(cin, generator=gen) + 0.5
+    shift = torch.randn(cin, generator=gen) * 0.3
+    wt = (torch.randn(cout, r, s, cin, generator=gen) / (r * s * cin) ** 0.5).to(bf16)
+    a = (x.float() * scale + shift).clamp(min=0).to(bf16)                 # what the kernel materialises in LDS
+    ref = F.conv2d(a.float().permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), stride=stride, padding=pad)
+    ref = nhwc(ref)
+    y = nn.conv2d_fwd(x.cuda(), wt.cuda(), stride, pad, in_scale=scale.cuda(), in_shift=shift.cuda(), in_relu=True)
+    err = (y.cpu().float() - ref).abs()
+    assert (err <= 2.0 ** -7 * ref.abs() + 1e-3).all(), err.max()
+    dy = torch.randn(ref.shape, generator=gen).to(bf16)
+    af = a.float().permute(0, 3, 1, 2)
+    wref = wt.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.conv2d(af, wref, stride=stride, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
+    dw = nn.conv2d_wgrad(x.cuda(), dy.cuda(), (r, s), stride, pad, in_scale=scale.cuda(), in_shift=shift.cuda(), in_relu=True)
+    ref_dw = wref.grad.permute(0, 2, 3, 1)
+    np.testing.assert_allclose(dw.cpu().numpy(), ref_dw.numpy(), rtol=2e-4, atol=2e-3 * float(ref_dw.abs().max()))
