@@ -38,6 +38,27 @@ _SIGNATURES = {
     "dali_conv2d_stat_tiles": [c_int, c_int, c_int, c_int],
     "dali_conv2d_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9,
     "dali_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_int],
+    "dali_bn_finalize": [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                         c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "dali_bn_act": [c_void_p] * 9 + [c_int, ctypes.c_int64, c_int, c_void_p],
+    "dali_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_int64, c_int] + [c_void_p] * 16,
+    "dali_maxpool_bn_fwd": [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p],
+    "dali_maxpool_bn_bwd": [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p],
+    "dali_head_pool_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "dali_head_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dali_bn1d_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
+                      c_void_p, c_void_p, c_void_p],
+    "dali_bn1d_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6,
+    "dali_resnet_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],
+    "dali_resnet_destroy": [c_void_p],
+    "dali_resnet_sizes": [c_void_p] + [c_void_p] * 6,
+    "dali_resnet_tensor_info": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "dali_resnet_stage_param_range": [c_void_p, c_int, c_void_p, c_void_p],
+    "dali_resnet_bind": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t],
+    "dali_resnet_refresh_weights": [c_void_p, c_void_p],
+    "dali_resnet_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "dali_resnet_backward": [c_void_p, c_void_p, c_void_p, c_int, c_int],
+    "dali_resnet_debug_tensor": [c_void_p, ctypes.c_char_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"dali_last_error": ctypes.c_char_p}
 

@@ -13,19 +13,9 @@
 // per-channel sum / sum-of-squares partials training-mode BatchNorm needs (deterministic, no atomics);
 // (c) the dgrad epilogue can add a residual gradient.
 #include "gemm_tile.h"
+#include "kernels.h"
 
 namespace dali {
-
-struct GatherGeom {
-    int Hout, Wout;            // pixel grid the GEMM N dimension enumerates (n, ho, wo)
-    int Hin, Win;              // grid of the gathered tensor (bounds)
-    int Ck;                    // channels per tap of the gathered tensor (multiple of 32)
-    int R, S, stride, pad;
-    int mode;                  // 0: hi = ho*stride - pad + r ; 1 (dgrad): hi = (ho + pad - r) / stride if divisible
-    long long img_pitch;       // elements between images of the gathered tensor
-    int row_pitch, pix_pitch;  // elements between rows / pixels
-    int lw, lhw;               // log2(Wout), log2(Hout*Wout) or -1
-};
 
 __device__ __forceinline__ void decode_pixel(const GatherGeom& g, int p, int& n, int& ho, int& wo) {
     if (g.lhw >= 0 && g.lw >= 0) {
@@ -82,18 +72,6 @@ __device__ __forceinline__ uint4 bn_relu_chunk(uint4 v, const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ------------------------------------------------------------------------------------------------
-struct IGemmArgs {
-    const uint16_t* W;        // [Cm][R*S*Ck]
-    const uint16_t* X;        // gathered tensor
-    uint16_t* O;              // [P][Cm]
-    const uint16_t* Res;      // optional residual [P][Cm], added in the epilogue
-    const float* in_scale;    // optional [Ck] affine (+ReLU) applied to X on load
-    const float* in_shift;
-    float* stats;             // optional [tiles_n][Cm][2] partial sum / sumsq of the fp32 results
-    int Cm, P, in_relu;
-    GatherGeom g;
-};
-
 template <int TN, bool IN_BN>
 struct PixelLoader {
     static constexpr int BCH = TN * 4 / 256;
@@ -235,16 +213,6 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
 // ({k0..k0+3} and {k0+8..k0+11}) fall on 8 distinct 32-byte bank groups of the 256-byte bank row.
 // Split-K over pixels: block (tile, ks) writes an fp32 slab; a second kernel sums the slabs in a fixed order.
 // ------------------------------------------------------------------------------------------------
-struct WGradArgs {
-    const uint16_t* dY;       // [P][Cm]
-    const uint16_t* X;        // gathered tensor
-    float* partial;           // [splits][Cm][Ntot]
-    const float* in_scale; const float* in_shift;
-    int Cm, P, Ntot, in_relu;
-    int splits, pix_per_split;    // pix_per_split multiple of 32
-    GatherGeom g;
-};
-
 __device__ __forceinline__ int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));

@@ -1,0 +1,78 @@
+// kernels.h -- host-side launchers shared between the single-op C ABI and the net plan.
+#pragma once
+#include "common.h"
+
+namespace dali {
+
+struct GatherGeom {
+    int Hout, Wout;            // pixel grid the GEMM N dimension enumerates (n, ho, wo)
+    int Hin, Win;              // grid of the gathered tensor (bounds)
+    int Ck;                    // channels per tap of the gathered tensor (multiple of 32)
+    int R, S, stride, pad;
+    int mode;                  // 0: hi = ho*stride - pad + r ; 1 (dgrad): hi = (ho + pad - r) / stride if divisible
+    long long img_pitch;       // elements between images of the gathered tensor
+    int row_pitch, pix_pitch;  // elements between rows / pixels
+    int lw, lhw;               // log2(Wout), log2(Hout*Wout) or -1
+};
+
+struct IGemmArgs {
+    const uint16_t* W;        // [Cm][R*S*Ck]
+    const uint16_t* X;        // gathered tensor
+    uint16_t* O;              // [P][Cm]
+    const uint16_t* Res;      // optional residual [P][Cm], added in the epilogue
+    const float* in_scale;    // optional [Ck] affine (+ReLU) applied to X on load
+    const float* in_shift;
+    float* stats;             // optional [tiles_n][Cm][2] partial sum / sumsq of the fp32 results
+    int Cm, P, in_relu;
+    GatherGeom g;
+};
+
+struct WGradArgs {
+    const uint16_t* dY;       // [P][Cm]
+    const uint16_t* X;        // gathered tensor
+    float* partial;           // [splits][Cm][Ntot]
+    const float* in_scale; const float* in_shift;
+    int Cm, P, Ntot, in_relu;
+    int splits, pix_per_split;    // pix_per_split multiple of 32
+    GatherGeom g;
+};
+
+
+struct BnBwdSide { const uint16_t* raw; const float* mean; const float* invstd; const float* scale; const float* shift; };
+
+// conv.hip
+int launch_igemm_conv(hipStream_t st, const IGemmArgs& a);
+int igemm_conv_stat_tiles(int Cm, int P);
+void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes);
+int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
+
+// nnops.hip
+int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
+                       float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd);
+int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                          float* scale, float* shift);
+int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,
+                  const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y);
+int bn_bwd_blocks(int P, int C, int* rows_per_block);
+size_t bn_bwd_partial_floats(int P, int C, bool dual);
+int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
+                  float* partial, float* coef_a, float* coef_b, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                  uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out);
+int launch_stem_pack_image(hipStream_t st, const float* img, int N, int H, int W, uint16_t* out);
+int launch_stem_pack_weight(hipStream_t st, const float* w, int Cout, uint16_t* out);
+int launch_stem_unpack_wgrad(hipStream_t st, const float* padded, int Cout, float* dw);
+int launch_maxpool_bn_fwd(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, int N, int H, int W, int C,
+                          uint16_t* out, uint8_t* arg);
+int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg, const uint16_t* raw, const float* mean, const float* invstd,
+                          const float* scale, int N, int H, int W, int C, float* partial, float* coef, float* dgamma, float* dbeta,
+                          uint16_t* draw);
+int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, float* f, int16_t* arg);
+int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, uint16_t* dx);
+int launch_bn1d_fwd(hipStream_t st, const float* x, int N, int C, const float* gamma, const float* beta, float* rm, float* rv, int training,
+                    float momentum, float eps, float* y, float* mean, float* invstd);
+int launch_bn1d_bwd(hipStream_t st, const float* x, const float* dy, int N, int C, const float* gamma, const float* mean, const float* invstd,
+                    float* dx, float* dgamma, float* dbeta);
+int launch_cast_bf16(hipStream_t st, const float* x, size_t n, uint16_t* y);
+int launch_weight_transpose(hipStream_t st, const uint16_t* w, int Co, int T, int Ci, uint16_t* wt);
+
+}  // namespace dali

@@ -1,0 +1,774 @@
+// nnops.hip -- the HBM-bound kernels around the convolutions of the ResNet-50-ReID trunk:
+// BatchNorm statistics/finalise/apply/backward, stem image/weight packing, max-pool (with the stem BN fused,
+// Encoders.py:333-335: conv1 -> bn1 -> maxpool, NO ReLU), global avg+max pool head (Encoders.py:341-345),
+// BatchNorm1d neck (Encoders.py:350), weight casts/transposes.  All activations NHWC bf16, math fp32.
+#include "kernels.h"
+
+namespace dali {
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
+    f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
+    f[4] = bf16_bits_to_f32(v.z & 0xffffu); f[5] = bf16_bits_to_f32(v.z >> 16);
+    f[6] = bf16_bits_to_f32(v.w & 0xffffu); f[7] = bf16_bits_to_f32(v.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+__device__ __forceinline__ void load8f(const float* __restrict__ p, float (&f)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalise: partial (sum, sumsq) [tiles][C][2] -> mean, invstd, scale = gamma*invstd,
+// shift = beta - mean*scale; running stats updated as torch does (momentum, unbiased variance).
+// One block per 32 channels: 8 tile-slices x 32 channels, fp64 accumulation.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float momentum, float eps, float* __restrict__ scale,
+                                                           float* __restrict__ shift, float* __restrict__ mean_out,
+                                                           float* __restrict__ invstd_out) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int t = sl; t < tiles; t += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)t * C + c) * 2);
+            a += (double)v.x; b += (double)v.y;
+        }
+    }
+    s1[sl][cl] = a; s2[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block output: y = relu( raw*scale+shift + identity ), identity = idn (bf16) or raw2*scale2+shift2.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_kernel(const uint16_t* __restrict__ raw, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const uint16_t* __restrict__ idn,
+                                                      const uint16_t* __restrict__ raw2, const float* __restrict__ scale2,
+                                                      const float* __restrict__ shift2, int relu, size_t chunks, int C,
+                                                      uint16_t* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 8) % (size_t)C);
+        float v[8], sc[8], sh[8];
+        unpack8(*reinterpret_cast<const uint4*>(raw + i * 8), v);
+        load8f(scale + c, sc); load8f(shift + c, sh);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = v[t] * sc[t] + sh[t];
+        if (idn) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4*>(idn + i * 8), r);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] += r[t];
+        } else if (raw2) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4*>(raw2 + i * 8), r);
+            load8f(scale2 + c, sc); load8f(shift2 + c, sh);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] += r[t] * sc[t] + sh[t];
+        }
+        if (relu) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        *reinterpret_cast<uint4*>(y + i * 8) = pack8(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward, two passes over [P][C] bf16 tensors.
+//   dz = g * mask,  mask = (ymask > 0) if ymask given else (raw*scale+shift > 0) if relu else 1
+//   reduce: S1[c] = sum dz, S2[c] = sum dz * xhat          (xhat = (raw-mean)*invstd)
+//   apply : draw = scale * (dz - S1/N - xhat * S2/N)
+// A second BN sharing the same dz (the downsample branch of a bottleneck) is handled in the same passes.
+// Work split: a thread owns one 16-byte channel chunk and strides over pixels; partials per block.
+// ------------------------------------------------------------------------------------------------
+template <bool DUAL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ymask,
+                                                             BnBwdSide a, BnBwdSide b, int relu, int P, int C,
+                                                             int rows_per_block, float* __restrict__ partial) {
+    extern __shared__ float red[];                  // [rows_in_flight][C][NV]
+    constexpr int NV = DUAL ? 3 : 2;                // S1, S2a, (S2b)
+    const int cpr = C >> 3;                         // chunks per row
+    const int rif = 256 / cpr;                      // rows in flight (C <= 2048)
+    const int col = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+    const int c = col * 8;
+    const int p0 = blockIdx.x * rows_per_block;
+    const int p1 = min(P, p0 + rows_per_block);
+    float s1[8], s2a[8], s2b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { s1[t] = 0.f; s2a[t] = 0.f; s2b[t] = 0.f; }
+    if (rsub < rif) {
+        float ma[8], ia[8], sa[8], ha[8], mb[8], ib[8];
+        load8f(a.mean + c, ma); load8f(a.invstd + c, ia);
+        if (!ymask && relu) { load8f(a.scale + c, sa); load8f(a.shift + c, ha); }
+        if (DUAL) { load8f(b.mean + c, mb); load8f(b.invstd + c, ib); }
+        for (int p = p0 + rsub; p < p1; p += rif) {
+            const size_t o = (size_t)p * C + c;
+            float gv[8], rv[8];
+            unpack8(*reinterpret_cast<const uint4*>(g + o), gv);
+            unpack8(*reinterpret_cast<const uint4*>(a.raw + o), rv);
+            if (ymask) {
+                float yv[8];
+                unpack8(*reinterpret_cast<const uint4*>(ymask + o), yv);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) gv[t] = yv[t] > 0.f ? gv[t] : 0.f;
+            } else if (relu) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) gv[t] = (rv[t] * sa[t] + ha[t]) > 0.f ? gv[t] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { s1[t] += gv[t]; s2a[t] += gv[t] * ((rv[t] - ma[t]) * ia[t]); }
+            if (DUAL) {
+                float r2[8];
+                unpack8(*reinterpret_cast<const uint4*>(b.raw + o), r2);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) s2b[t] += gv[t] * ((r2[t] - mb[t]) * ib[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float* d = red + ((size_t)rsub * C + c + t) * NV;
+            d[0] = s1[t]; d[1] = s2a[t];
+            if (DUAL) d[2] = s2b[t];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * NV; e += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rif; ++r) s += red[(size_t)r * C * NV + e];
+        partial[(size_t)blockIdx.x * C * NV + e] = s;
+    }
+}
+
+// partial [blocks][C][NV] -> coef [C][3] = (scale, S1/N, S2/N), dgamma = S2, dbeta = S1 (accumulate optional)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C, int NV,
+                                                               int which, double count, const float* __restrict__ scale,
+                                                               float* __restrict__ coef, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, const float* __restrict__ invstd_unused) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int t = sl; t < blocks; t += 8) {
+            const float* p = partial + ((size_t)t * C + c) * NV;
+            a += (double)p[0]; b += (double)p[which];
+        }
+    }
+    s1[sl][cl] = a; s2[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        coef[c * 3 + 0] = scale[c];
+        coef[c * 3 + 1] = (float)(a / count);
+        coef[c * 3 + 2] = (float)(b / count);
+        dgamma[c] = (float)b;
+        dbeta[c] = (float)a;
+    }
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ymask,
+                                                            BnBwdSide a, BnBwdSide b, const float* __restrict__ coef_a,
+                                                            const float* __restrict__ coef_b, int relu, size_t chunks, int C,
+                                                            uint16_t* __restrict__ draw_a, uint16_t* __restrict__ draw_b,
+                                                            uint16_t* __restrict__ dz_out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 8) % (size_t)C);
+        float gv[8], rv[8], ma[8], ia[8];
+        unpack8(*reinterpret_cast<const uint4*>(g + i * 8), gv);
+        unpack8(*reinterpret_cast<const uint4*>(a.raw + i * 8), rv);
+        load8f(a.mean + c, ma); load8f(a.invstd + c, ia);
+        if (ymask) {
+            float yv[8];
+            unpack8(*reinterpret_cast<const uint4*>(ymask + i * 8), yv);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gv[t] = yv[t] > 0.f ? gv[t] : 0.f;
+        } else if (relu) {
+            float sa[8], ha[8];
+            load8f(a.scale + c, sa); load8f(a.shift + c, ha);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gv[t] = (rv[t] * sa[t] + ha[t]) > 0.f ? gv[t] : 0.f;
+        }
+        float o[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float* cf = coef_a + (c + t) * 3;
+            o[t] = cf[0] * (gv[t] - cf[1] - ((rv[t] - ma[t]) * ia[t]) * cf[2]);
+        }
+        if (DUAL) {
+            float r2[8], mb[8], ib[8], o2[8];
+            unpack8(*reinterpret_cast<const uint4*>(b.raw + i * 8), r2);
+            load8f(b.mean + c, mb); load8f(b.invstd + c, ib);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float* cf = coef_b + (c + t) * 3;
+                o2[t] = cf[0] * (gv[t] - cf[1] - ((r2[t] - mb[t]) * ib[t]) * cf[2]);
+            }
+            *reinterpret_cast<uint4*>(draw_b + i * 8) = pack8(o2);
+        }
+        if (dz_out) *reinterpret_cast<uint4*>(dz_out + i * 8) = pack8(gv);     // may alias g (same index, read first)
+        *reinterpret_cast<uint4*>(draw_a + i * 8) = pack8(o);                 // may alias g when dz_out is null
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem packing.  Image: fp32 NCHW [N,3,H,W] -> bf16 [N][H+6][Wp][4] zero-padded (3 px border, 4th channel 0,
+// Wp = W+8).  A 7x7/2 tap row (8 taps x 4 ch = 32 bf16 = 64 B) is then one contiguous, aligned k-tile.
+// Weight: fp32 [64][7][7][3] (OHWI, the channels_last storage of conv1.weight) -> bf16 [64][7][8][4].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_pack_image_kernel(const float* __restrict__ img, int N, int H, int W, int Hp, int Wp,
+                                                               uint16_t* __restrict__ out) {
+    const size_t total = (size_t)N * Hp * Wp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int wp = (int)(i % Wp);
+        const int hp = (int)((i / Wp) % Hp);
+        const int n = (int)(i / ((size_t)Wp * Hp));
+        const int h = hp - 3, w = wp - 3;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const size_t base = ((size_t)n * 3 * H + h) * W + w;
+            v[0] = img[base]; v[1] = img[base + (size_t)H * W]; v[2] = img[base + 2 * (size_t)H * W];
+        }
+        *reinterpret_cast<uint2*>(out + i * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], 0.f));
+    }
+}
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, int Cout, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over Cout*7*8*4
+    if (i >= Cout * 224) return;
+    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % 7, o = i / 224;
+    float v = 0.f;
+    if (c < 3 && s < 7) v = w[((o * 7 + r) * 7 + s) * 3 + c];
+    out[i] = f32_to_bf16_bits(v);
+}
+__global__ void stem_unpack_wgrad_kernel(const float* __restrict__ padded, int Cout, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // over Cout*7*7*3
+    if (i >= Cout * 147) return;
+    const int c = i % 3, s = (i / 3) % 7, r = (i / 21) % 7, o = i / 147;
+    dw[i] = padded[((o * 7 + r) * 8 + s) * 4 + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3/2 pad-1 max-pool over z = raw*scale+shift (the stem BN, no ReLU), NHWC, 8 channels per thread.
+// arg = tap index 0..8 of the first maximum in (r,s) scan order (torch's rule).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const uint16_t* __restrict__ raw, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int N, int H, int W, int C,
+                                                              int Ho, int Wo, uint16_t* __restrict__ out, uint8_t* __restrict__ arg) {
+    const int cpr = C >> 3;
+    const size_t total = (size_t)N * Ho * Wo * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cc = (int)(i % cpr) * 8;
+        const size_t pix = i / cpr;
+        const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Wo * Ho));
+        float sc[8], sh[8], best[8];
+        int bi[8];
+        load8f(scale + cc, sc); load8f(shift + cc, sh);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { best[t] = -__builtin_inff(); bi[t] = 0; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int h = ho * 2 - 1 + r;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int w = wo * 2 - 1 + s;
+                if (w < 0 || w >= W) continue;
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(raw + (((size_t)n * H + h) * W + w) * C + cc), v);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float z = v[t] * sc[t] + sh[t];
+                    if (z > best[t]) { best[t] = z; bi[t] = r * 3 + s; }
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(out + pix * C + cc) = pack8(best);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { lo |= (uint32_t)bi[t] << (8 * t); hi |= (uint32_t)bi[t + 4] << (8 * t); }
+        *reinterpret_cast<uint2*>(arg + pix * C + cc) = make_uint2(lo, hi);
+    }
+}
+
+// dz[n,h,w,c] = sum over the (<=4) windows containing (h,w) of dp[window] * [arg[window] == tap of (h,w)]
+__device__ __forceinline__ void maxpool_gather_dz(const uint16_t* __restrict__ dp, const uint8_t* __restrict__ arg, int n, int h, int w,
+                                                  int cc, int C, int Ho, int Wo, float (&dz)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dz[t] = 0.f;
+    const int ho_lo = (h >= 1) ? (h - 1 + 1) / 2 : 0;      // ceil((h-1)/2)
+    const int ho_hi = min(Ho - 1, (h + 1) / 2);
+    const int wo_lo = (w >= 1) ? (w - 1 + 1) / 2 : 0;
+    const int wo_hi = min(Wo - 1, (w + 1) / 2);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            const int tap = (h - (ho * 2 - 1)) * 3 + (w - (wo * 2 - 1));
+            const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + cc;
+            const uint2 av = *reinterpret_cast<const uint2*>(arg + o);
+            float g[8];
+            unpack8(*reinterpret_cast<const uint4*>(dp + o), g);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int a = (t < 4 ? (av.x >> (8 * t)) : (av.y >> (8 * (t - 4)))) & 0xff;
+                if (a == tap) dz[t] += g[t];
+            }
+        }
+}
+
+// pass 1: partial sums of dz and dz*xhat over the stem output;  pass 2: d_raw = scale*(dz - S1/N - xhat*S2/N)
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_kernel(const uint16_t* __restrict__ dp, const uint8_t* __restrict__ arg,
+                                                                     const uint16_t* __restrict__ raw, const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd, int N, int H, int W, int C,
+                                                                     int Ho, int Wo, int rows_per_block, float* __restrict__ partial) {
+    extern __shared__ float red[];                  // [rif][C][2]
+    const int cpr = C >> 3, rif = 256 / cpr;
+    const int col = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+    const int cc = col * 8;
+    const int P = N * H * W;
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(P, p0 + rows_per_block);
+    float s1[8], s2[8], m[8], iv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+    if (rsub < rif) {
+        load8f(mean + cc, m); load8f(invstd + cc, iv);
+        for (int p = p0 + rsub; p < p1; p += rif) {
+            const int w = p % W, h = (p / W) % H, n = p / (W * H);
+            float dz[8], rv[8];
+            maxpool_gather_dz(dp, arg, n, h, w, cc, C, Ho, Wo, dz);
+            unpack8(*reinterpret_cast<const uint4*>(raw + (size_t)p * C + cc), rv);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { s1[t] += dz[t]; s2[t] += dz[t] * ((rv[t] - m[t]) * iv[t]); }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { red[((size_t)rsub * C + cc + t) * 2] = s1[t]; red[((size_t)rsub * C + cc + t) * 2 + 1] = s2[t]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * 2; e += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rif; ++r) s += red[(size_t)r * C * 2 + e];
+        partial[(size_t)blockIdx.x * C * 2 + e] = s;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const uint16_t* __restrict__ dp, const uint8_t* __restrict__ arg,
+                                                                    const uint16_t* __restrict__ raw, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                                    int N, int H, int W, int C, int Ho, int Wo, uint16_t* __restrict__ draw) {
+    const int cpr = C >> 3;
+    const size_t total = (size_t)N * H * W * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cc = (int)(i % cpr) * 8;
+        const size_t p = i / cpr;
+        const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+        float dz[8], rv[8], m[8], iv[8], o[8];
+        maxpool_gather_dz(dp, arg, n, h, w, cc, C, Ho, Wo, dz);
+        unpack8(*reinterpret_cast<const uint4*>(raw + p * C + cc), rv);
+        load8f(mean + cc, m); load8f(invstd + cc, iv);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float* cf = coef + (cc + t) * 3;
+            o[t] = cf[0] * (dz[t] - cf[1] - ((rv[t] - m[t]) * iv[t]) * cf[2]);
+        }
+        *reinterpret_cast<uint4*>(draw + p * C + cc) = pack8(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head: f[n,c] = mean_hw x + max_hw x (Encoders.py:341-345), fp32 out, argmax kept for the backward.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_pool_fwd_kernel(const uint16_t* __restrict__ x, int N, int HW, int C,
+                                                             float* __restrict__ f, int16_t* __restrict__ arg) {
+    const int cpr = C >> 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * cpr) return;
+    const int cc = (i % cpr) * 8, n = i / cpr;
+    float sum[8], best[8];
+    int bi[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { sum[t] = 0.f; best[t] = -__builtin_inff(); bi[t] = 0; }
+    for (int p = 0; p < HW; ++p) {
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p) * C + cc), v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sum[t] += v[t]; if (v[t] > best[t]) { best[t] = v[t]; bi[t] = p; } }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        f[(size_t)n * C + cc + t] = sum[t] / (float)HW + best[t];
+        arg[(size_t)n * C + cc + t] = (int16_t)bi[t];
+    }
+}
+__global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restrict__ df, const int16_t* __restrict__ arg, int N, int HW,
+                                                             int C, uint16_t* __restrict__ dx) {
+    const int cpr = C >> 3;
+    const size_t total = (size_t)N * HW * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cc = (int)(i % cpr) * 8;
+        const size_t pix = i / cpr;
+        const int p = (int)(pix % HW), n = (int)(pix / HW);
+        float g[8], o[8];
+        load8f(df + (size_t)n * C + cc, g);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] = g[t] / (float)HW + ((int)arg[(size_t)n * C + cc + t] == p ? g[t] : 0.f);
+        *reinterpret_cast<uint4*>(dx + pix * C + cc) = pack8(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d neck on fp32 [N,C] (one thread per channel; N rows are L2 resident).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int N, int C, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
+                                                        int training, float momentum, float eps, float* __restrict__ y,
+                                                        float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float mean, invstd;
+    if (training) {
+        double s = 0.0;
+        for (int n = 0; n < N; ++n) s += (double)x[(size_t)n * C + c];
+        const double m = s / N;
+        double v = 0.0;
+        for (int n = 0; n < N; ++n) { const double d = (double)x[(size_t)n * C + c] - m; v += d * d; }
+        const double var = v / N;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (rm) {
+            const double unbiased = N > 1 ? v / (N - 1) : var;
+            rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+            rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = rm[c];
+        invstd = 1.0f / sqrtf(rv[c] + eps);
+    }
+    if (mean_out) { mean_out[c] = mean; invstd_out[c] = invstd; }
+    const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
+    for (int n = 0; n < N; ++n) y[(size_t)n * C + c] = x[(size_t)n * C + c] * sc + sh;
+}
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int C,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ dx,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float m = mean[c], iv = invstd[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float g = dy[(size_t)n * C + c];
+        s1 += (double)g; s2 += (double)g * (double)((x[(size_t)n * C + c] - m) * iv);
+    }
+    dgamma[c] = (float)s2; dbeta[c] = (float)s1;
+    const float a = (float)(s1 / N), b = (float)(s2 / N), sc = gamma[c] * iv;
+    for (int n = 0; n < N; ++n) {
+        const float xh = (x[(size_t)n * C + c] - m) * iv;
+        dx[(size_t)n * C + c] = sc * (dy[(size_t)n * C + c] - a - xh * b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight layout helpers: fp32 -> bf16 cast (flat), and [Co][T][Ci] -> [Ci][T][Co] bf16 for dgrad.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, size_t n, uint16_t* __restrict__ y) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            *reinterpret_cast<uint2*>(y + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        } else {
+            for (size_t e = i; e < n; ++e) y[e] = f32_to_bf16_bits(x[e]);
+        }
+    }
+}
+// one block transposes a 32(co) x 32(ci) tile of one tap
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const uint16_t* __restrict__ w, int Co, int T, int Ci,
+                                                                uint16_t* __restrict__ wt) {
+    __shared__ uint16_t tile[32][33];
+    const int tiles_ci = (Ci + 31) / 32, tiles_co = (Co + 31) / 32;
+    const int b = blockIdx.x;
+    const int tci = b % tiles_ci, tco = (b / tiles_ci) % tiles_co, tap = b / (tiles_ci * tiles_co);
+    const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;
+    for (int y = y0; y < 32; y += 8) {
+        const int co = tco * 32 + y, ci = tci * 32 + x;
+        tile[y][x] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * Ci + ci] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int y = y0; y < 32; y += 8) {
+        const int ci = tci * 32 + y, co = tco * 32 + x;
+        if (ci < Ci && co < Co) wt[((size_t)ci * T + tap) * Co + co] = tile[x][y];
+    }
+}
+
+static inline int grid_for(size_t work_items, int cap = 16384) {
+    size_t b = (work_items + 255) / 256;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- host launchers (shared with the net plan) ----------------------------------------------------
+int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
+                       float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, tiles, C, count, gamma, beta, rm, rv, momentum,
+                       eps, scale, shift, mean, invstd);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                          float* scale, float* shift) {
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, rm, rv, eps, C, scale, shift);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,
+                  const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y) {
+    const size_t chunks = elems / 8;
+    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(chunks)), dim3(256), 0, st, raw, scale, shift, idn, raw2, scale2, shift2, relu, chunks, C, y);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+// Number of partial blocks the reduce pass uses for a [P][C] tensor
+int bn_bwd_blocks(int P, int C, int* rows_per_block) {
+    const int rif = 256 / (C / 8);
+    int blocks = (P + rif * 8 - 1) / (rif * 8);           // >= 8 rows per thread
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    int rpb = (P + blocks - 1) / blocks;
+    rpb = (rpb + rif - 1) / rif * rif;
+    blocks = (P + rpb - 1) / rpb;
+    *rows_per_block = rpb;
+    return blocks;
+}
+int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
+                  float* partial, float* coef_a, float* coef_b, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                  uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out) {
+    int rpb;
+    const int blocks = bn_bwd_blocks(P, C, &rpb);
+    const int rif = 256 / (C / 8);
+    const bool dual = b != nullptr;
+    const int NV = dual ? 3 : 2;
+    const size_t lds = (size_t)rif * C * NV * sizeof(float);
+    BnBwdSide bb = dual ? *b : a;
+    if (dual) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), lds, st, g, ymask, a, bb, relu, P, C, rpb, partial);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), lds, st, g, ymask, a, bb, relu, P, C, rpb, partial);
+    }
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, blocks, C, NV, 1, (double)P, a.scale, coef_a,
+                       dgamma_a, dbeta_a, (const float*)nullptr);
+    DALI_LAUNCH_CHECK();
+    if (dual) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, blocks, C, NV, 2, (double)P, bb.scale, coef_b,
+                           dgamma_b, dbeta_b, (const float*)nullptr);
+        DALI_LAUNCH_CHECK();
+    }
+    const size_t chunks = (size_t)P * C / 8;
+    if (dual) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, a, bb, coef_a, coef_b, relu, chunks, C, draw_a, draw_b, dz_out);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, a, bb, coef_a, coef_a, relu, chunks, C, draw_a, draw_b, dz_out);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+size_t bn_bwd_partial_floats(int P, int C, bool dual) {
+    int rpb;
+    return (size_t)bn_bwd_blocks(P, C, &rpb) * C * (dual ? 3 : 2);
+}
+int launch_stem_pack_image(hipStream_t st, const float* img, int N, int H, int W, uint16_t* out) {
+    const int Hp = H + 6, Wp = W + 8;
+    hipLaunchKernelGGL(stem_pack_image_kernel, dim3(grid_for((size_t)N * Hp * Wp)), dim3(256), 0, st, img, N, H, W, Hp, Wp, out);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_stem_pack_weight(hipStream_t st, const float* w, int Cout, uint16_t* out) {
+    hipLaunchKernelGGL(stem_pack_weight_kernel, dim3((Cout * 224 + 255) / 256), dim3(256), 0, st, w, Cout, out);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_stem_unpack_wgrad(hipStream_t st, const float* padded, int Cout, float* dw) {
+    hipLaunchKernelGGL(stem_unpack_wgrad_kernel, dim3((Cout * 147 + 255) / 256), dim3(256), 0, st, padded, Cout, dw);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_maxpool_bn_fwd(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, int N, int H, int W, int C,
+                          uint16_t* out, uint8_t* arg) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_bn_fwd_kernel, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(256), 0, st, raw, scale, shift, N, H, W, C,
+                       Ho, Wo, out, arg);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg, const uint16_t* raw, const float* mean, const float* invstd,
+                          const float* scale, int N, int H, int W, int C, float* partial, float* coef, float* dgamma, float* dbeta,
+                          uint16_t* draw) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int P = N * H * W;
+    int rpb;
+    const int blocks = bn_bwd_blocks(P, C, &rpb);
+    const int rif = 256 / (C / 8);
+    hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)rif * C * 2 * sizeof(float), st, dp, arg, raw, mean, invstd,
+                       N, H, W, C, Ho, Wo, rpb, partial);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, blocks, C, 2, 1, (double)P, scale, coef, dgamma,
+                       dbeta, (const float*)nullptr);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 8))), dim3(256), 0, st, dp, arg, raw, mean, invstd, coef, N, H,
+                       W, C, Ho, Wo, draw);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, float* f, int16_t* arg) {
+    hipLaunchKernelGGL(head_pool_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, st, x, N, HW, C, f, arg);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, uint16_t* dx) {
+    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, st, df, arg, N, HW, C, dx);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_bn1d_fwd(hipStream_t st, const float* x, int N, int C, const float* gamma, const float* beta, float* rm, float* rv, int training,
+                    float momentum, float eps, float* y, float* mean, float* invstd) {
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, N, C, gamma, beta, rm, rv, training, momentum, eps, y, mean, invstd);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_bn1d_bwd(hipStream_t st, const float* x, const float* dy, int N, int C, const float* gamma, const float* mean, const float* invstd,
+                    float* dx, float* dgamma, float* dbeta) {
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, dy, N, C, gamma, mean, invstd, dx, dgamma, dbeta);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_cast_bf16(hipStream_t st, const float* x, size_t n, uint16_t* y) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, st, x, n, y);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_weight_transpose(hipStream_t st, const uint16_t* w, int Co, int T, int Ci, uint16_t* wt) {
+    const int blocks = ((Ci + 31) / 32) * ((Co + 31) / 32) * T;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3(blocks), dim3(256), 0, st, w, Co, T, Ci, wt);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+}  // namespace dali
+
+// ---- single-op C ABI (parity tests; the net plan calls the launchers directly) ------------------------------
+using namespace dali;
+
+extern "C" int dali_bn_finalize(dali_ctx* ctx, void* stream, const float* partial, int tiles, int C, double count,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
+    DALI_REQUIRE(ctx && partial && gamma && beta && scale && shift && mean && invstd, "dali_bn_finalize: null argument");
+    DALI_REQUIRE(tiles > 0 && C > 0 && count > 0, "dali_bn_finalize: bad sizes");
+    return launch_bn_finalize((hipStream_t)stream, partial, tiles, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale,
+                              shift, mean, invstd);
+}
+
+extern "C" int dali_bn_act(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift,
+                           const uint16_t* identity, const uint16_t* raw2, const float* scale2, const float* shift2, int relu,
+                           int64_t pixels, int C, uint16_t* y) {
+    DALI_REQUIRE(ctx && raw && scale && shift && y, "dali_bn_act: null argument");
+    DALI_REQUIRE(C % 8 == 0 && pixels >= 0, "dali_bn_act: C must be a multiple of 8");
+    DALI_REQUIRE(!(identity && raw2), "dali_bn_act: identity and raw2 are exclusive");
+    DALI_REQUIRE(!raw2 || (scale2 && shift2), "dali_bn_act: raw2 needs scale2/shift2");
+    if (pixels == 0) return DALI_OK;
+    return launch_bn_act((hipStream_t)stream, raw, scale, shift, identity, raw2, scale2, shift2, relu, (size_t)pixels * C, C, y);
+}
+
+extern "C" int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* ymask, int relu, int64_t pixels, int C,
+                           const uint16_t* raw_a, const float* mean_a, const float* invstd_a, const float* scale_a, const float* shift_a,
+                           const uint16_t* raw_b, const float* mean_b, const float* invstd_b, const float* scale_b,
+                           float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, uint16_t* draw_a, uint16_t* draw_b,
+                           uint16_t* dz_out) {
+    DALI_REQUIRE(ctx && g && raw_a && mean_a && invstd_a && scale_a && dgamma_a && dbeta_a && draw_a, "dali_bn_bwd: null argument");
+    DALI_REQUIRE(C % 8 == 0 && C <= 2048 && pixels > 0 && pixels < (1ll << 31), "dali_bn_bwd: C must be a multiple of 8, <= 2048");
+    DALI_REQUIRE(ymask || !relu || shift_a, "dali_bn_bwd: relu mask needs ymask or scale/shift");
+    const bool dual = raw_b != nullptr;
+    DALI_REQUIRE(!dual || (mean_b && invstd_b && scale_b && dgamma_b && dbeta_b && draw_b), "dali_bn_bwd: incomplete second side");
+    const size_t pf = bn_bwd_partial_floats((int)pixels, C, dual);
+    const size_t need = align_up(pf * 4, 256) + 2 * align_up((size_t)C * 12, 256);
+    char* ws = static_cast<char*>(workspace(ctx, need));
+    if (!ws) return DALI_ERR_NOMEM;
+    float* partial = reinterpret_cast<float*>(ws);
+    float* coef_a = reinterpret_cast<float*>(ws + align_up(pf * 4, 256));
+    float* coef_b = reinterpret_cast<float*>(ws + align_up(pf * 4, 256) + align_up((size_t)C * 12, 256));
+    BnBwdSide a{raw_a, mean_a, invstd_a, scale_a, shift_a};
+    BnBwdSide b{raw_b, mean_b, invstd_b, scale_b, nullptr};
+    return launch_bn_bwd((hipStream_t)stream, g, ymask, a, dual ? &b : nullptr, relu, (int)pixels, C, partial, coef_a, coef_b, dgamma_a, dbeta_a,
+                         dgamma_b, dbeta_b, draw_a, draw_b, dz_out);
+}
+
+extern "C" int dali_maxpool_bn_fwd(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift, int n, int h,
+                                   int w, int C, uint16_t* out, uint8_t* arg) {
+    DALI_REQUIRE(ctx && raw && scale && shift && out && arg, "dali_maxpool_bn_fwd: null argument");
+    DALI_REQUIRE(C % 8 == 0 && n > 0 && h > 0 && w > 0, "dali_maxpool_bn_fwd: bad shape");
+    return launch_maxpool_bn_fwd((hipStream_t)stream, raw, scale, shift, n, h, w, C, out, arg);
+}
+
+extern "C" int dali_maxpool_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* dpool, const uint8_t* arg, const uint16_t* raw,
+                                   const float* mean, const float* invstd, const float* scale, int n, int h, int w, int C,
+                                   float* dgamma, float* dbeta, uint16_t* draw) {
+    DALI_REQUIRE(ctx && dpool && arg && raw && mean && invstd && scale && dgamma && dbeta && draw, "dali_maxpool_bn_bwd: null argument");
+    DALI_REQUIRE(C % 8 == 0 && C <= 2048, "dali_maxpool_bn_bwd: C must be a multiple of 8, <= 2048");
+    const size_t pf = bn_bwd_partial_floats(n * h * w, C, false);
+    const size_t need = align_up(pf * 4, 256) + align_up((size_t)C * 12, 256);
+    char* ws = static_cast<char*>(workspace(ctx, need));
+    if (!ws) return DALI_ERR_NOMEM;
+    return launch_maxpool_bn_bwd((hipStream_t)stream, dpool, arg, raw, mean, invstd, scale, n, h, w, C, reinterpret_cast<float*>(ws),
+                                 reinterpret_cast<float*>(ws + align_up(pf * 4, 256)), dgamma, dbeta, draw);
+}
+
+extern "C" int dali_head_pool_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, int n, int hw, int C, float* f, int16_t* arg) {
+    DALI_REQUIRE(ctx && x && f && arg, "dali_head_pool_fwd: null argument");
+    DALI_REQUIRE(C % 8 == 0 && hw > 0 && hw < 32768, "dali_head_pool_fwd: bad shape");
+    return launch_head_pool_fwd((hipStream_t)stream, x, n, hw, C, f, arg);
+}
+extern "C" int dali_head_pool_bwd(dali_ctx* ctx, void* stream, const float* df, const int16_t* arg, int n, int hw, int C, uint16_t* dx) {
+    DALI_REQUIRE(ctx && df && arg && dx, "dali_head_pool_bwd: null argument");
+    DALI_REQUIRE(C % 8 == 0 && hw > 0, "dali_head_pool_bwd: bad shape");
+    return launch_head_pool_bwd((hipStream_t)stream, df, arg, n, hw, C, dx);
+}
+extern "C" int dali_bn1d_fwd(dali_ctx* ctx, void* stream, const float* x, int n, int C, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, int training, float momentum, float eps, float* y, float* mean,
+                             float* invstd) {
+    DALI_REQUIRE(ctx && x && gamma && beta && y, "dali_bn1d_fwd: null argument");
+    DALI_REQUIRE(training || (running_mean && running_var), "dali_bn1d_fwd: eval mode needs running statistics");
+    return launch_bn1d_fwd((hipStream_t)stream, x, n, C, gamma, beta, running_mean, running_var, training, momentum, eps, y, mean, invstd);
+}
+extern "C" int dali_bn1d_bwd(dali_ctx* ctx, void* stream, const float* x, const float* dy, int n, int C, const float* gamma,
+                             const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta) {
+    DALI_REQUIRE(ctx && x && dy && gamma && mean && invstd && dx && dgamma && dbeta, "dali_bn1d_bwd: null argument");
+    return launch_bn1d_bwd((hipStream_t)stream, x, dy, n, C, gamma, mean, invstd, dx, dgamma, dbeta);
+}

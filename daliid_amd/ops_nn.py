@@ -54,3 +54,108 @@ def conv2d_wgrad(x, dy, rs, stride=1, pad=0, in_scale=None, in_shift=None, in_re
                                              _lib.ptr(in_scale), _lib.ptr(in_shift), int(in_relu), int(accumulate)),
                "dali_conv2d_wgrad")
     return out
+
+
+# ---- BatchNorm / pooling / head single ops -------------------------------------------------------------------
+def _f32(n, dev):
+    return torch.empty(n, device=dev, dtype=torch.float32)
+
+
+def bn_finalize(partial, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    tiles, C, _ = partial.shape
+    dev = partial.device
+    scale, shift, mean, invstd = _f32(C, dev), _f32(C, dev), _f32(C, dev), _f32(C, dev)
+    _lib.check(_lib.lib().dali_bn_finalize(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(partial, torch.float32), tiles, C, float(count),
+                                            _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                            momentum, eps, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd)),
+               "dali_bn_finalize")
+    return scale, shift, mean, invstd
+
+
+def bn_act(raw, scale, shift, identity=None, raw2=None, scale2=None, shift2=None, relu=True):
+    C = raw.shape[-1]
+    y = torch.empty_like(raw)
+    _lib.check(_lib.lib().dali_bn_act(_lib.ctx(raw.device), _lib.stream_ptr(), _lib.ptr(raw, bf16), _lib.ptr(scale), _lib.ptr(shift),
+                                       _lib.ptr(identity), _lib.ptr(raw2), _lib.ptr(scale2), _lib.ptr(shift2), int(relu),
+                                       raw.numel() // C, C, _lib.ptr(y)), "dali_bn_act")
+    return y
+
+
+def bn_bwd(g, raw_a, mean_a, invstd_a, scale_a, shift_a=None, ymask=None, relu=True, side_b=None, want_dz=False):
+    """-> (draw_a, dgamma_a, dbeta_a[, draw_b, dgamma_b, dbeta_b][, dz])"""
+    C = g.shape[-1]
+    dev = g.device
+    pixels = g.numel() // C
+    draw_a, dga, dba = torch.empty_like(g), _f32(C, dev), _f32(C, dev)
+    draw_b = dgb = dbb = None
+    rb = mb = ib = sb = None
+    if side_b is not None:
+        rb, mb, ib, sb = side_b
+        draw_b, dgb, dbb = torch.empty_like(g), _f32(C, dev), _f32(C, dev)
+    dz = torch.empty_like(g) if want_dz else None
+    _lib.check(_lib.lib().dali_bn_bwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(g, bf16), _lib.ptr(ymask), int(relu), pixels, C,
+                                       _lib.ptr(raw_a, bf16), _lib.ptr(mean_a), _lib.ptr(invstd_a), _lib.ptr(scale_a), _lib.ptr(shift_a),
+                                       _lib.ptr(rb), _lib.ptr(mb), _lib.ptr(ib), _lib.ptr(sb), _lib.ptr(dga), _lib.ptr(dba),
+                                       _lib.ptr(dgb), _lib.ptr(dbb), _lib.ptr(draw_a), _lib.ptr(draw_b), _lib.ptr(dz)), "dali_bn_bwd")
+    out = (draw_a, dga, dba)
+    if side_b is not None:
+        out += (draw_b, dgb, dbb)
+    if want_dz:
+        out += (dz,)
+    return out
+
+
+def maxpool_bn_fwd(raw, scale, shift):
+    n, h, w, C = raw.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty(n, ho, wo, C, device=raw.device, dtype=bf16)
+    arg = torch.empty(n, ho, wo, C, device=raw.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().dali_maxpool_bn_fwd(_lib.ctx(raw.device), _lib.stream_ptr(), _lib.ptr(raw, bf16), _lib.ptr(scale), _lib.ptr(shift),
+                                               n, h, w, C, _lib.ptr(out), _lib.ptr(arg)), "dali_maxpool_bn_fwd")
+    return out, arg
+
+
+def maxpool_bn_bwd(dpool, arg, raw, mean, invstd, scale):
+    n, h, w, C = raw.shape
+    dev = raw.device
+    draw, dg, db = torch.empty_like(raw), _f32(C, dev), _f32(C, dev)
+    _lib.check(_lib.lib().dali_maxpool_bn_bwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(dpool, bf16), _lib.ptr(arg), _lib.ptr(raw, bf16),
+                                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(scale), n, h, w, C, _lib.ptr(dg), _lib.ptr(db),
+                                               _lib.ptr(draw)), "dali_maxpool_bn_bwd")
+    return draw, dg, db
+
+
+def head_pool_fwd(x):
+    n, h, w, C = x.shape
+    f = torch.empty(n, C, device=x.device, dtype=torch.float32)
+    arg = torch.empty(n, C, device=x.device, dtype=torch.int16)
+    _lib.check(_lib.lib().dali_head_pool_fwd(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16), n, h * w, C, _lib.ptr(f), _lib.ptr(arg)),
+               "dali_head_pool_fwd")
+    return f, arg
+
+
+def head_pool_bwd(df, arg, hw_shape):
+    n, C = df.shape
+    h, w = hw_shape
+    dx = torch.empty(n, h, w, C, device=df.device, dtype=bf16)
+    _lib.check(_lib.lib().dali_head_pool_bwd(_lib.ctx(df.device), _lib.stream_ptr(), _lib.ptr(df, torch.float32), _lib.ptr(arg), n, h * w, C,
+                                              _lib.ptr(dx)), "dali_head_pool_bwd")
+    return dx
+
+
+def bn1d_fwd(x, gamma, beta, running_mean=None, running_var=None, training=True, momentum=0.1, eps=1e-5):
+    n, C = x.shape
+    y, mean, invstd = torch.empty_like(x), _f32(C, x.device), _f32(C, x.device)
+    _lib.check(_lib.lib().dali_bn1d_fwd(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, torch.float32), n, C, _lib.ptr(gamma), _lib.ptr(beta),
+                                         _lib.ptr(running_mean), _lib.ptr(running_var), int(training), momentum, eps, _lib.ptr(y),
+                                         _lib.ptr(mean), _lib.ptr(invstd)), "dali_bn1d_fwd")
+    return y, mean, invstd
+
+
+def bn1d_bwd(x, dy, gamma, mean, invstd):
+    n, C = x.shape
+    dx, dg, db = torch.empty_like(x), _f32(C, x.device), _f32(C, x.device)
+    _lib.check(_lib.lib().dali_bn1d_bwd(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, torch.float32), _lib.ptr(dy, torch.float32), n, C,
+                                         _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db)),
+               "dali_bn1d_bwd")
+    return dx, dg, db

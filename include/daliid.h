@@ -115,6 +115,75 @@ int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x, const uint
                       int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
                       const float* in_scale, const float* in_shift, int in_relu, int accumulate);
 
+/* BatchNorm2d pieces (torch.nn.BatchNorm2d inside torchvision's Bottleneck, and Encoders.py:333).  Training-mode
+ * statistics come from the conv epilogue partials; finalize turns them into scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale and updates the running statistics exactly like torch (momentum, unbiased var). */
+int dali_bn_finalize(dali_ctx* ctx, void* stream, const float* partial, int tiles, int C, double count,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, float* scale, float* shift, float* mean, float* invstd);
+/* y = relu?(raw*scale+shift + identity) with identity = identity tensor | raw2*scale2+shift2 | nothing (bottleneck tail). */
+int dali_bn_act(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift,
+                const uint16_t* identity, const uint16_t* raw2, const float* scale2, const float* shift2, int relu,
+                int64_t pixels, int C, uint16_t* y);
+/* Backward of z = bn(raw) followed by an optional ReLU whose mask is (ymask > 0) if ymask is given, else
+ * (raw*scale+shift > 0).  g = gradient after the ReLU.  Writes d(raw) (bf16), dgamma, dbeta; with a second side
+ * (raw_b...) the same masked gradient also flows through a second BatchNorm (the downsample branch).  dz_out
+ * (nullable, may alias g) receives the masked gradient.  draw_a may alias g when dz_out is null. */
+int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* ymask, int relu, int64_t pixels, int C,
+                const uint16_t* raw_a, const float* mean_a, const float* invstd_a, const float* scale_a, const float* shift_a,
+                const uint16_t* raw_b, const float* mean_b, const float* invstd_b, const float* scale_b,
+                float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, uint16_t* draw_a, uint16_t* draw_b,
+                uint16_t* dz_out);
+/* Stem tail (Encoders.py:333-335): out = maxpool3x3/2,pad1( raw*scale+shift ), no ReLU; arg = winning tap 0..8. */
+int dali_maxpool_bn_fwd(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift, int n, int h,
+                        int w, int C, uint16_t* out, uint8_t* arg);
+int dali_maxpool_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* dpool, const uint8_t* arg, const uint16_t* raw,
+                        const float* mean, const float* invstd, const float* scale, int n, int h, int w, int C,
+                        float* dgamma, float* dbeta, uint16_t* draw);
+/* Head (Encoders.py:341-345): f[n,c] = mean_hw x + max_hw x (fp32), and its backward. */
+int dali_head_pool_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, int n, int hw, int C, float* f, int16_t* arg);
+int dali_head_pool_bwd(dali_ctx* ctx, void* stream, const float* df, const int16_t* arg, int n, int hw, int C, uint16_t* dx);
+/* BatchNorm1d neck (Encoders.py:350) on fp32 [n,C]. */
+int dali_bn1d_fwd(dali_ctx* ctx, void* stream, const float* x, int n, int C, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, int training, float momentum, float eps, float* y, float* mean,
+                  float* invstd);
+int dali_bn1d_bwd(dali_ctx* ctx, void* stream, const float* x, const float* dy, int n, int C, const float* gamma,
+                  const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta);
+
+/* ---- net plan: Encoders.ResNet50ReID forward / backward (Encoders.py:306-351) ------------------------ *
+ * The plan owns topology + launch order; the caller owns storage: flat fp32 params / grads / BN running
+ * statistics, and one byte arena (activations, bf16 weight images, scratch).  Tensor names and order follow
+ * torchvision's state_dict ("conv1.weight", "bn1.weight", "layer1.0.conv1.weight", ..., "last_bn.bias"),
+ * conv weights are stored [cout][r][s][cin] (the channels_last storage of a logical OIHW tensor). */
+typedef struct dali_resnet dali_resnet;
+typedef struct {
+    int batch, height, width;   /* images: fp32 NCHW [batch,3,height,width]; height % 32 == 0, width % 16 == 0 */
+    int layers[4];              /* bottlenecks per stage: {3,4,6,3} for ResNet-50 */
+    int width_base;             /* 64 for ResNet-50 (32 allowed for test-size nets) */
+} dali_resnet_cfg;
+
+int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dali_resnet** out);
+int dali_resnet_destroy(dali_resnet* net);
+int dali_resnet_sizes(const dali_resnet* net, int64_t* param_elems, int64_t* buffer_elems, int64_t* arena_bytes,
+                      int* feat_dim, int* n_params, int* n_buffers);
+/* kind 0: parameter, 1: buffer (running_mean / running_var).  offset/numel in fp32 elements of the flat storage. */
+int dali_resnet_tensor_info(const dali_resnet* net, int kind, int index, char* name, int name_cap, int64_t* offset,
+                            int64_t* numel, int* shape4, int* ndim);
+int dali_resnet_stage_param_range(const dali_resnet* net, int stage, int64_t* begin, int64_t* end);
+/* All storages 256-byte aligned; grads may be null for inference-only use. */
+int dali_resnet_bind(dali_resnet* net, float* params, float* grads, float* buffers, void* arena, size_t arena_bytes);
+/* Rebuild the bf16 operand images from the fp32 master weights (call after every optimizer step / state load). */
+int dali_resnet_refresh_weights(dali_resnet* net, void* stream);
+/* images fp32 NCHW -> emb fp32 [batch, feat_dim].  training != 0: batch statistics + running-stat update
+ * (model.train()); else running statistics (model.eval()).  Stands under `model_online(batch_imgs)`
+ * (train_encodersKIT.py:197) and `model(batch_gpu)` (getFeatures.py:61). */
+int dali_resnet_forward(dali_resnet* net, void* stream, const float* images, int training, float* emb);
+/* Backward of the last training forward, stages stage_begin..stage_end (0: neck+head+layer4, 1: layer3,
+ * 2: layer2, 3: layer1+stem); fills the flat gradient buffer (overwrites, no accumulation).
+ * Stands under `batch_loss.backward()` (train_encodersKIT.py:215). */
+int dali_resnet_backward(dali_resnet* net, void* stream, const float* d_emb, int stage_begin, int stage_end);
+int dali_resnet_debug_tensor(dali_resnet* net, const char* name, void** ptr, int64_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,85 @@
+"""Oracle (rounding-matched): the ResNet-50-ReID train-mode forward/backward in fp32 torch on CPU with a
+bf16 round-trip inserted at exactly the points where the HIP pipeline stores a tensor in bf16.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Why it exists: a randomly initialised BatchNorm ResNet amplifies perturbations layer over layer, so the
+bf16-storage HIP path drifts from the pure-fp32 oracle (oracle/resnet50_reid.py) by rounding noise alone;
+that drift says nothing about correctness.  This twin rounds where the kernels round, so what is left is fp32
+summation order -- and any real indexing / fusion bug.
+
+Rounding points mirrored (daliid_amd/csrc/resnet_plan.hip):
+  images and conv weights -> bf16 operands; every raw conv output stored bf16; relu(bn(raw)) rounded to bf16 when
+  it is formed in the consumer's operand load; block outputs y and the pooled stem output stored bf16; in the
+  backward pass the gradients of those same tensors are stored bf16.  BatchNorm statistics come from the fp32
+  accumulators (the un-rounded conv result) and are applied to the rounded tensor; weight gradients stay fp32.
+"""
+import torch
+import torch.nn.functional as F
+
+
+class _Q(torch.autograd.Function):
+    """bf16 round-trip in the forward AND on the gradient in the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+class _QW(torch.autograd.Function):
+    """bf16 round-trip of a weight operand; its gradient stays fp32."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+Q = _Q.apply
+QW = _QW.apply
+
+
+def _bn_train(u, uq, bn, eps=1e-5):
+    """statistics from the un-rounded conv result u, affine applied to the stored (rounded) tensor uq."""
+    dims = (0, 2, 3) if u.dim() == 4 else (0,)
+    mean = u.mean(dims)
+    var = u.var(dims, unbiased=False)
+    scale = bn.weight / torch.sqrt(var + eps)
+    shift = bn.bias - mean * scale
+    shp = (1, -1, 1, 1) if u.dim() == 4 else (1, -1)
+    return uq * scale.view(shp) + shift.view(shp)
+
+
+def _conv(x, conv):
+    return F.conv2d(x, QW(conv.weight), stride=conv.stride, padding=conv.padding)
+
+
+def forward_matched(model, x):
+    """model: oracle.resnet50_reid.ResNet50ReID (its parameters receive the gradients). Train-mode forward."""
+    x = Q(x)
+    u = _conv(x, model.conv1)
+    z = _bn_train(u, Q(u), model.bn1)                   # no ReLU after the stem BN (Encoders.py:334)
+    x = Q(F.max_pool2d(z, 3, 2, 1))
+    for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
+        for blk in layer:
+            u1 = _conv(x, blk.conv1)
+            a1 = Q(F.relu(_bn_train(u1, Q(u1), blk.bn1)))
+            u2 = _conv(a1, blk.conv2)
+            a2 = Q(F.relu(_bn_train(u2, Q(u2), blk.bn2)))
+            u3 = _conv(a2, blk.conv3)
+            out = _bn_train(u3, Q(u3), blk.bn3)
+            if blk.downsample is not None:
+                ud = _conv(x, blk.downsample[0])
+                idn = _bn_train(ud, Q(ud), blk.downsample[1])
+            else:
+                idn = x
+            x = Q(F.relu(out + idn))
+    f = x.mean((2, 3)) + F.adaptive_max_pool2d(x, 1).flatten(1)     # Encoders.py:341-345
+    return _bn_train(f, f, model.last_bn)               # BatchNorm1d neck in fp32
