@@ -49,6 +49,13 @@ _SIGNATURES = {
     "dali_bn1d_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                       c_void_p, c_void_p, c_void_p],
     "dali_bn1d_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6,
+    "dali_center_loss_fwd": [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_void_p],
+    "dali_center_loss_bwd": [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_float, c_void_p],
+    "dali_proxy_loss_fwd": [c_void_p] * 6 + [c_float, c_int, c_int] + [c_void_p] * 5,
+    "dali_proxy_loss_bwd": [c_void_p] * 5 + [c_int, c_int, c_void_p, c_float, c_int, c_void_p],
+    "dali_proxy_kmax": [],
+    "dali_adam_step": [c_void_p] * 6 + [ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p],
+    "dali_ema_update": [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_float],
     "dali_resnet_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],
     "dali_resnet_destroy": [c_void_p],
     "dali_resnet_sizes": [c_void_p] + [c_void_p] * 6,

@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
                 if (metric == DALI_METRIC_L2SQ) {
                     const float gg = (g0 + r < ng) ? gsq[g0 + r] : 0.f;
                     v[r] = qq + gg - 2.0f * dot;
+                } else if (metric == DALI_METRIC_DOT) {
+                    v[r] = dot;
                 } else {
                     v[r] = 1.0f - dot;
                 }
@@ -368,7 +370,7 @@ extern "C" int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const uint16_
     DALI_REQUIRE(ctx && q_hi && g_hi && q_sq && g_sq && out, "dali_pairdist_prepared: null argument");
     DALI_REQUIRE((q_lo == nullptr) == (g_lo == nullptr), "dali_pairdist_prepared: q_lo and g_lo must both be set or both null");
     DALI_REQUIRE(nq >= 0 && ng >= 0 && d > 0, "dali_pairdist_prepared: bad shape nq=%d ng=%d d=%d", nq, ng, d);
-    DALI_REQUIRE(metric == DALI_METRIC_COSINE || metric == DALI_METRIC_L2SQ, "dali_pairdist_prepared: bad metric %d", metric);
+    DALI_REQUIRE(metric == DALI_METRIC_COSINE || metric == DALI_METRIC_L2SQ || metric == DALI_METRIC_DOT, "dali_pairdist_prepared: bad metric %d", metric);
     DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist_prepared: out must be 16-byte aligned");
     if (nq == 0 || ng == 0) return DALI_OK;
     return launch_pairdist((hipStream_t)stream, g_hi, g_lo, g_sq, q_hi, q_lo, q_sq, nq, ng, (d + 31) & ~31, metric,
@@ -379,7 +381,7 @@ extern "C" int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const 
                              int metric, int precision, int normalize, float* out) {
     DALI_REQUIRE(ctx && Q && G && out, "dali_pairdist: null argument");
     DALI_REQUIRE(nq >= 0 && ng >= 0 && d > 0, "dali_pairdist: bad shape nq=%d ng=%d d=%d", nq, ng, d);
-    DALI_REQUIRE(metric == DALI_METRIC_COSINE || metric == DALI_METRIC_L2SQ, "dali_pairdist: bad metric %d", metric);
+    DALI_REQUIRE(metric == DALI_METRIC_COSINE || metric == DALI_METRIC_L2SQ || metric == DALI_METRIC_DOT, "dali_pairdist: bad metric %d", metric);
     DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist: bad precision %d", precision);
     DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist: out must be 16-byte aligned");
     if (nq == 0 || ng == 0) return DALI_OK;

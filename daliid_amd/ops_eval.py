@@ -4,10 +4,10 @@ import torch
 
 from . import _lib
 
-METRIC_COSINE, METRIC_L2SQ = 0, 1
+METRIC_COSINE, METRIC_L2SQ, METRIC_DOT = 0, 1, 2
 PREC_BF16X3, PREC_BF16 = 0, 1
 _PREC = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
-_METRIC = {"cosine": METRIC_COSINE, "l2sq": METRIC_L2SQ}
+_METRIC = {"cosine": METRIC_COSINE, "l2sq": METRIC_L2SQ, "dot": METRIC_DOT}
 
 
 def l2norm_rows(x, eps=0.0, return_norms=False):

@@ -46,7 +46,8 @@ int dali_ctx_reserve(dali_ctx* ctx, size_t bytes);
 
 /* ---- evaluation path: validateModels.validate (validateModels.py:35-58) ------------------------- */
 typedef enum { DALI_METRIC_COSINE = 0,   /* 1 - q.g         validateModels.py:47, evaluate.py:291 */
-               DALI_METRIC_L2SQ = 1      /* |q|^2+|g|^2-2q.g  (square of the commented cdist, :45) */
+               DALI_METRIC_L2SQ = 1,     /* |q|^2+|g|^2-2q.g  (square of the commented cdist, :45) */
+               DALI_METRIC_DOT = 2       /* q.g : the similarity GEMMs of the loss heads (losses.py:62, :277) */
 } dali_metric;
 typedef enum { DALI_PREC_BF16X3 = 0,     /* split-bf16 (hi*hi+hi*lo+lo*hi), fp32 accumulate: ~1e-6 abs */
                DALI_PREC_BF16 = 1        /* single bf16 product, fp32 accumulate: ~1e-4 abs on unit rows */
@@ -149,6 +150,40 @@ int dali_bn1d_fwd(dali_ctx* ctx, void* stream, const float* x, int n, int C, con
                   float* invstd);
 int dali_bn1d_bwd(dali_ctx* ctx, void* stream, const float* x, const float* dy, int n, int C, const float* gamma,
                   const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta);
+
+/* ---- loss heads (train_encodersKIT.py:200-208), fp32 --------------------------------------------------- *
+ * S is the similarity matrix fn @ C^T (dali_pairdist with DALI_METRIC_DOT).  labels are int32 codes shared between
+ * the batch and the center / proxy label arrays; w[i] is the distortion weight table[samples_distortion[i]]
+ * (losses.py:42-52).  Both losses are  sum_i num_i / sum_i den_i  with batch-global sums: *_fwd returns the local
+ * sums[2] = {sum num, sum den} (all-reduce them across data-parallel ranks), *_bwd takes the global denominator. */
+
+/* BatchWeightedCenterLoss (losses.py:39-88).  rowstat[nb][4] = {num_i, den_i, argmax_j, max_j softmax}. */
+int dali_center_loss_fwd(dali_ctx* ctx, void* stream, const float* S, const int32_t* labels, const int32_t* center_labels,
+                         const float* w, float tau, int nb, int NC, float* rowstat, float* sums);
+/* dS[nb][NC] = gscale * d(sum num / denom)/dS. */
+int dali_center_loss_bwd(dali_ctx* ctx, void* stream, const float* S, const int32_t* labels, const int32_t* center_labels,
+                         const float* w, float tau, int nb, int NC, const float* denom, float gscale, float* dS);
+/* BatchWeightedProxyLoss (losses.py:273-341).  rowstat[nb][2] = {num_i, den_i}; sel_idx / sel_coef [nb][2*K] hold the
+ * selected proxies (K positives then K negatives, -1 padded, K = dali_proxy_kmax()) and d num_i / d S_ij.
+ * status[0] != 0 if some row had more than K positives (they are truncated: treat as an error). */
+int dali_proxy_loss_fwd(dali_ctx* ctx, void* stream, const float* S, const int32_t* labels, const int32_t* proxy_labels,
+                        const float* w, float tau, int nb, int NP, float* rowstat, float* sums, int32_t* sel_idx,
+                        float* sel_coef, int32_t* status);
+/* dfn[nb][D] (= or +=) gscale/denom * sum_sel coef * proxies[sel][:]. */
+int dali_proxy_loss_bwd(dali_ctx* ctx, void* stream, const int32_t* sel_idx, const float* sel_coef, const float* proxies, int nb,
+                        int D, const float* denom, float gscale, int accumulate, float* dfn);
+int dali_proxy_kmax(void);
+
+/* ---- optimizer side of the hot loop, on the flat fp32 storages ------------------------------------------- */
+/* torch.optim.Adam step (L2 weight decay added to the gradient; mainKIT.py:99, train_encodersKIT.py:214-216):
+ * g' = grad_scale*g + wd*p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  weights_sqsum (nullable, device) receives sum p^2 of the
+ * updated parameters (the trainer's "weights_sum", train_encodersKIT.py:229-231). */
+int dali_adam_step(dali_ctx* ctx, void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                   float* weights_sqsum);
+/* momentum = beta*momentum + (1-beta)*online  (train_encodersKIT.py:218-226), flat. */
+int dali_ema_update(dali_ctx* ctx, void* stream, float* momentum, const float* online, int64_t n, float beta);
 
 /* ---- net plan: Encoders.ResNet50ReID forward / backward (Encoders.py:306-351) ------------------------ *
  * The plan owns topology + launch order; the caller owns storage: flat fp32 params / grads / BN running
