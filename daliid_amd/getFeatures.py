@@ -1,0 +1,59 @@
+"""Mirror of the reference's ``getFeatures.extractFeatures`` (getFeatures.py:47-71): eval-mode batched inference
+over a dataset index, result concatenated in order.
+
+Image decode / resize is outside the accelerated path: it goes through a pluggable loader.  The default
+loader reproduces ``sample.transform_person`` (getFeatures.py:18-19: PIL bicubic resize, ToTensor, ImageNet
+mean/std) with PIL + numpy; synthetic datasets register an in-memory loader with ``set_image_loader``.
+"""
+import time
+
+import numpy as np
+import torch
+
+_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
+_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
+
+
+def pil_loader(paths, img_height, img_width, turb=None):
+    """getFeatures.py:18-19 / :31-41: read_image -> Resize((H,W), bicubic) -> ToTensor -> Normalize."""
+    from PIL import Image
+    out = np.empty((len(paths), 3, img_height, img_width), dtype=np.float32)
+    for i, p in enumerate(paths):
+        img = Image.open(p).convert("RGB").resize((img_width, img_height), Image.BICUBIC)
+        out[i] = (np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0 - _MEAN) / _STD
+    return torch.from_numpy(out)
+
+
+_loader = pil_loader
+
+
+def set_image_loader(fn):
+    """fn(paths: sequence[str], img_height, img_width, turb=None) -> float tensor [n,3,H,W] (CPU or CUDA)."""
+    global _loader
+    _loader = fn if fn is not None else pil_loader
+
+
+def get_image_loader():
+    return _loader
+
+
+def extractFeatures(subset, img_height, img_width, model, batch_size, gpu_index=0, dataset=None, turbulance_dir_path=None,
+                    turb_strength=None, keep_on_device=False, verbose=True):
+    """-> fp32 [N, D] features in dataset order; on the CPU like the reference (getFeatures.py:62) unless
+    ``keep_on_device`` (the in-tree callers keep them on the GPU and skip the D2H/H2D round trip)."""
+    model.eval()
+    dev = torch.device("cuda", gpu_index)
+    paths = [row[0] for row in subset]
+    start = time.time()
+    chunks = []
+    turb = None if not turbulance_dir_path else (turbulance_dir_path, turb_strength, dataset)
+    with torch.no_grad():
+        for b in range(0, len(paths), batch_size):
+            batch = _loader(paths[b:b + batch_size], img_height, img_width, turb)
+            chunks.append(model(batch.to(dev, non_blocking=True)))
+    fvs = torch.cat(chunks, 0) if chunks else torch.empty(0, 0, device=dev)
+    if not keep_on_device:
+        fvs = fvs.cpu()
+    if verbose:
+        print("Features extracted in %.2f seconds" % (time.time() - start))
+    return fvs

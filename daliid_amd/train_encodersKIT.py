@@ -1,0 +1,211 @@
+"""Mirror of the reference's ``train_encodersKIT.py`` for the path in scope: ``trainer`` (:45-249),
+``selectProxiesByTriagulation`` (:252-284), ``collate_fn_PK`` (:289-290), ``samplePKBatches`` (:292-403, PK sampling
+and clean/turbulence pairing; decode + augmentation go through the pluggable loader of daliid_amd.getFeatures).
+
+One epoch of ``trainer.train`` = full-train-set inference -> class centers + 5 farthest-point proxies per class ->
+one pass of PK batches {forward, L2-normalise(+1e-9), center + lambda*proxy loss, backward, Adam, EMA, sum ||theta||^2}.
+The hot loop issues only HIP kernels (C ABI) and, with a process group, two RCCL collectives per step; nothing
+synchronises with the host until the epoch summary is printed."""
+import numpy as np
+import torch
+
+from . import _lib, ops_eval, optim
+from .getFeatures import extractFeatures, get_image_loader
+from .losses import LossHeads, _codes, _sample_weights
+
+np.random.seed(12)
+torch.manual_seed(12)
+
+
+def selectProxiesByTriagulation(X, num_proxies=5):
+    """train_encodersKIT.py:252-284: farthest-point sampling; first pick ``np.random.choice(n)``, then repeatedly the
+    point whose minimum distance to the chosen set is largest (``argsort(...)[-1]``).
+    -> (indices LongTensor, max pairwise distance among the chosen)."""
+    dist = torch.cdist(X, X, p=2.0)
+    n = dist.shape[0]
+    running = torch.ones(n, device=X.device) * torch.max(dist)
+    proxies = [int(np.random.choice(n))]
+    num_proxies = min(num_proxies, n)
+    for j in range(num_proxies - 1):
+        running = torch.minimum(running, dist[proxies[j]])
+        proxies.append(int(torch.argsort(running, stable=True)[-1]))
+    proxies = torch.tensor(proxies, dtype=torch.long, device=X.device)
+    return proxies, torch.max(dist[proxies, :][:, proxies]).item()
+
+
+def build_centers_and_proxies(fvs, labels, num_proxies=5):
+    """train_encodersKIT.py:113-156 on device-resident features: per class, proxies by farthest-point sampling and
+    the center = mean of the un-normalised embeddings; both L2-normalised (no epsilon).
+    -> (centers, centers_labels, all_proxies, proxies_labels, mean_max_distance)"""
+    labels = np.asarray(labels)
+    centers_labels = np.unique(labels)
+    order = np.argsort(labels, kind="stable")
+    bounds = np.searchsorted(labels[order], centers_labels, side="left").tolist() + [len(labels)]
+    order_t = torch.from_numpy(order).to(fvs.device)
+    centers, all_proxies, proxies_labels, mean_max = [], [], [], 0.0
+    for ci, label in enumerate(centers_labels):
+        rows = fvs[order_t[bounds[ci]:bounds[ci + 1]]]
+        idx, max_dist = selectProxiesByTriagulation(rows, num_proxies=num_proxies)
+        mean_max += max_dist
+        all_proxies.append(rows[idx])
+        proxies_labels.append(np.array([label] * len(idx)))
+        centers.append(rows.mean(dim=0, keepdim=True))
+    centers = ops_eval.l2norm_rows(torch.cat(centers, 0).contiguous(), 0.0)
+    all_proxies = ops_eval.l2norm_rows(torch.cat(all_proxies, 0).contiguous(), 0.0)
+    return centers, centers_labels, all_proxies, np.concatenate(proxies_labels), mean_max / len(centers_labels)
+
+
+def collate_fn_PK(batch):
+    return batch
+
+
+class samplePKBatches:
+    """train_encodersKIT.py:292-403.  ``__getitem__(idx)`` -> (images [k or 2k,3,H,W], labels, distortion levels) for
+    the idx-th identity of a shuffled identity list: up to K images of that identity; with ``kind_of_transform == 1``
+    every image is paired with a turbulence-distorted copy of random strength 1..5 (distortion level = strength)."""
+
+    def __init__(self, dataset, images, labels, img_height, img_width, turbulance_dir_path, kind_of_transform, K=4, turb_strength=0):
+        self.images_names = images[:, 0]
+        self.labels = np.asarray(labels)
+        self.labels_set = np.unique(labels)
+        self.K = K
+        np.random.shuffle(self.labels_set)
+        self.img_height, self.img_width = img_height, img_width
+        self.dataset, self.turbulance_dir_path, self.kind_of_transform = dataset, turbulance_dir_path, kind_of_transform
+
+    def __len__(self):
+        return len(self.labels_set)
+
+    def __getitem__(self, idx):
+        pid = self.labels_set[idx]
+        names = self.images_names[self.labels == pid]
+        sel = np.random.choice(names.shape[0], size=min(names.shape[0], self.K), replace=False)
+        loader = get_image_loader()
+        clean = loader(list(names[sel]), self.img_height, self.img_width, None)
+        if self.kind_of_transform == 0:
+            imgs, dist = clean, np.zeros(len(sel), dtype=np.int32)
+        else:
+            strengths = np.random.choice([1, 2, 3, 4, 5], size=len(sel))
+            turb = torch.cat([loader([names[s]], self.img_height, self.img_width, (self.turbulance_dir_path, int(t), self.dataset))
+                              for s, t in zip(sel, strengths)], 0)
+            imgs = torch.stack((clean, turb.to(clean.device)), 1).flatten(0, 1)          # clean, distorted, clean, distorted ...
+            dist = np.stack((np.zeros(len(sel), dtype=np.int32), strengths.astype(np.int32)), 1).reshape(-1)
+        return imgs, torch.ones(imgs.shape[0]) * float(pid), dist
+
+
+class trainer(object):
+    """train_encodersKIT.py:45-249, same constructor arguments and attributes."""
+
+    def __init__(self, dataset, selected_images, model_name, labels_dict, img_height, img_width, turbulance_dir_path, is_clean_training,
+                 kind_of_transform, optimizer, P, K, tau, beta, lambda_proxy, number_of_epoches, model_online, model_momentum, gpu_indexes,
+                 version, process_group=None):
+        self.dataset, self.selected_images, self.model_name, self.labels_dict = dataset, selected_images, model_name, labels_dict
+        self.img_height, self.img_width = img_height, img_width
+        self.turbulance_dir_path, self.is_clean_training, self.kind_of_transform = turbulance_dir_path, is_clean_training, kind_of_transform
+        self.num_proxies = 5
+        self.optimizer = optimizer
+        self.P, self.K, self.tau, self.beta, self.lambda_proxy = P, K, tau, beta, lambda_proxy
+        self.number_of_epoches = number_of_epoches
+        self.model_online, self.model_momentum = model_online, model_momentum
+        self.gpu_indexes, self.version = gpu_indexes, version
+        self.process_group = process_group
+        self._net = getattr(model_online, "module", model_online)
+        self._mom = getattr(model_momentum, "module", model_momentum)
+        self._adam = optimizer if isinstance(optimizer, optim.FusedAdam) else optim.FusedAdam.from_torch(optimizer, self._net)
+        self._dp = DataParallelReducer(self._net, process_group) if process_group is not None else None
+        self.last_epoch_stats = None
+
+    # ---- epoch-level: inference over the train set, centers, proxies (train_encodersKIT.py:104-156) ----
+    def build_targets(self, selected_images, selected_labels):
+        self.model_online.eval()
+        print("Number of samples for proxies generation: %d" % selected_images.shape[0])
+        fvs = extractFeatures(selected_images, self.img_height, self.img_width, self.model_online, 500, gpu_index=self.gpu_indexes[0],
+                              keep_on_device=True)
+        centers, centers_labels, all_proxies, proxies_labels, mean_max = build_centers_and_proxies(fvs, selected_labels, self.num_proxies)
+        pd = ops_eval.pairdist(all_proxies, all_proxies, metric="l2sq").clamp_(min=0).sqrt_()      # the cdist statistic, :148-153
+        same = torch.from_numpy(proxies_labels[:, None] == proxies_labels[None, :]).to(pd.device)
+        min_distance = torch.where(same, pd.max(), pd).min().item()
+        print("Mean Max Proxies Positive Distances: %.3f, Min Negative Distance: %.3f" % (mean_max, min_distance))
+        return LossHeads(centers, centers_labels, all_proxies, proxies_labels, self.tau, self.lambda_proxy, self.process_group)
+
+    # ---- one optimisation step on a device-resident batch (train_encodersKIT.py:191-231) ----
+    def train_step(self, heads, batch_imgs, labels_codes, w, acc):
+        """acc: device fp32 [6] running sums (center, proxy, total, weights_sum, steps, _)."""
+        net = self._net
+        emb = net._run_forward(batch_imgs, training=True)
+        fn = ops_eval.l2norm_rows(emb, 1e-9)                                          # :198
+        stats, dfn = heads(fn, labels_codes, w)                                       # :200-208 (+ gradient)
+        d_emb = ops_eval.l2norm_rows_bwd(emb, dfn, 1e-9)
+        for stage in range(4):                                                        # :215 backward
+            net._backward_stage(d_emb, stage)
+            if self._dp is not None:
+                self._dp.reduce_stage(stage)
+        if self._dp is not None:
+            self._dp.finish()
+        self._adam.step()                                                             # :216
+        optim.ema_update(self._mom, net, self.beta)                                   # :218-226
+        total, lc, lp = LossHeads.losses_from_stats(stats, self.lambda_proxy)
+        acc[0] += lc; acc[1] += lp; acc[2] += total
+        acc[3:4] += self._adam.weights_sqsum                                          # :229-231
+        acc[4] += 1
+        return stats
+
+    def train(self, selected_images, selected_labels, number_of_iterations, current_epoch):
+        dev = torch.device("cuda", self.gpu_indexes[0])
+        event_dataset = samplePKBatches(self.dataset, selected_images, selected_labels, self.img_height, self.img_width,
+                                        self.turbulance_dir_path, self.kind_of_transform, K=self.K)
+        num_classes = np.unique(selected_labels).shape[0]
+        bs = min(self.P, num_classes)
+        heads = self.build_targets(selected_images, selected_labels)
+        self.model_online.train()
+        self.model_momentum.eval()
+        for inner_iter in np.arange(number_of_iterations):
+            print("Iteration number: %d/%d" % (inner_iter + 1, number_of_iterations))
+            order = np.random.permutation(len(event_dataset))                         # DataLoader(shuffle=True, drop_last=True)
+            n_batches = len(order) // bs
+            acc = torch.zeros(6, device=dev, dtype=torch.float32)
+            for b in range(n_batches):
+                parts = [event_dataset[i] for i in order[b * bs:(b + 1) * bs]]
+                batch_imgs = torch.cat([p[0] for p in parts], 0).to(dev, non_blocking=True)
+                if batch_imgs.shape[0] <= 2:                                          # :194-195
+                    continue
+                labels_codes = _codes(torch.cat([p[1] for p in parts], 0), dev)
+                w = _sample_weights(torch.from_numpy(np.concatenate([p[2] for p in parts])), current_epoch, self.number_of_epoches, dev)
+                self.train_step(heads, batch_imgs, labels_codes, w, acc)
+            a = acc.cpu().numpy()                                                      # the only host sync of the epoch
+            nb = max(n_batches, 1)
+            self.last_epoch_stats = dict(center=a[0] / nb, proxy=a[1] / nb, loss=a[2] / nb, weights_sum=a[3] / nb, steps=int(a[4]))
+            print("Batches computed: %d" % int(a[4]))
+            print("Mean Center Loss: %.7f, Mean Proxy Loss: %.7f" % (a[0] / nb, a[1] / nb))
+            print("Mean Final Loss: %.7f" % (a[2] / nb))
+            print("Mean Weights Sum: %.2f" % (a[3] / nb))
+        self.model_online.eval()
+        self.model_momentum.eval()
+
+
+class DataParallelReducer:
+    """One process per GPU: SUM all-reduce (RCCL over xGMI) of the flat gradient buffer, one bucket per backward stage,
+    issued on a side stream as soon as the stage's kernels are enqueued so it overlaps the next stage's backward.
+    The loss normalisers are global (LossHeads), so the reduction is a SUM, not a mean."""
+
+    def __init__(self, net, process_group):
+        self.net, self.pg = net, process_group
+        self.stream = torch.cuda.Stream(device=net.flat_params.device)
+        self.ready = torch.cuda.Event()
+        self.ranges = None
+        self.works = []
+
+    def reduce_stage(self, stage):
+        if self.ranges is None:
+            self.ranges = [self.net._bwd_plan.stage_range(s) for s in range(4)]
+        b, e = self.ranges[stage]
+        self.ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.ready)
+            self.works.append(torch.distributed.all_reduce(self.net.flat_grads[b:e], group=self.pg, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        torch.cuda.current_stream().wait_stream(self.stream)
