@@ -187,7 +187,8 @@ class LossHeads:
         _, sums_p, sel_idx, sel_coef, self.status = proxy_fwd(Sp, labels, self.plabels, w, self.tau)
         stats = torch.cat((sums_c, sums_p))
         if self.pg is not None:
-            torch.distributed.all_reduce(stats, group=self.pg)
+            from .parallel import allreduce_loss_stats
+            allreduce_loss_stats(stats, self.pg)
         dS = center_bwd(Sc, labels, self.clabels, w, self.tau, stats[1:2])
         dfn = pairdist(dS, self.centers_t, metric="dot")
         proxy_bwd(sel_idx, sel_coef, self.proxies, stats[3:4], gscale=self.lam, out=dfn, accumulate=True)

@@ -1,0 +1,83 @@
+"""Data parallelism for the train step: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" on CPU for the tests).  The reference uses single-process ``nn.DataParallel`` (Encoders.py:39-40): a
+per-step weight broadcast, a gather of the outputs and a reduce of all gradients to GPU 0.  Here every rank holds
+the weights, runs the step on its shard of the PK batch (identities split across ranks, local BatchNorm statistics =
+DataParallel semantics, Encoders.py:88-89) and exchanges exactly
+
+  1. one all-reduce(SUM) of 4 floats: numerator / denominator of the two loss heads (their normalisers are global over
+     the batch: losses.py:77, :338), issued between the heads' forward and backward;
+  2. one all-reduce(SUM, not mean) of the flat gradient buffer per backward stage (4 buckets: layer4+neck 15.0 M,
+     layer3 7.1 M, layer2 1.2 M, layer1+stem 0.2 M floats), each launched on a side stream as soon as its stage is
+     enqueued so it overlaps the remaining backward.  xGMI is a point-to-point mesh: few large buckets beat many small.
+Adam and the EMA then run redundantly on identical data on every rank (no weight broadcast, ever).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run sets them)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return world, rank, local
+
+
+def shard_identities(ids, rank, world):
+    """Split the P identities of a PK batch across ranks (contiguous blocks; every rank gets P/world ids x K images).
+    Any row split is valid because both heads are sums of per-row terms against fixed centers/proxies."""
+    n = len(ids)
+    if n % world != 0:
+        raise ValueError("P=%d identities do not divide over %d ranks" % (n, world))
+    per = n // world
+    return ids[rank * per:(rank + 1) * per]
+
+
+def allreduce_loss_stats(stats, group=None):
+    """stats [4] = local (center_num, center_den, proxy_num, proxy_den) -> global sums, in place."""
+    if group is not None or (dist.is_initialized() and dist.get_world_size() > 1):
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
+class GradReducer:
+    """SUM all-reduce of the flat gradient buffer in per-stage buckets.  On CUDA the collectives run on a side stream
+    behind an event recorded right after the stage's kernels were enqueued (overlap with the next stage's backward);
+    on CPU tensors (gloo tests) they run synchronously."""
+
+    def __init__(self, flat_grads, ranges, group=None):
+        self.flat, self.ranges, self.group = flat_grads, list(ranges), group
+        self.cuda = flat_grads.is_cuda
+        self.works = []
+        if self.cuda:
+            self.stream = torch.cuda.Stream(device=flat_grads.device)
+            self.ready = torch.cuda.Event()
+
+    def reduce_stage(self, stage):
+        b, e = self.ranges[stage]
+        if e <= b:
+            return
+        if not self.cuda:
+            dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        self.ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.ready)
+            self.works.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)

