@@ -116,11 +116,13 @@ class ResNet50ReID(nn.Module):
             leaf.register_parameter(attr, nn.Parameter(view))
             self._grad_views[name] = self._view(self.flat_grads, off, numel, shape)
             self._param_names.append(name)
-        for name, off, numel, shape in probe.tensor_table(1):
+        table1 = probe.tensor_table(1)
+        self.flat_nbt = torch.zeros(sum(1 for t in table1 if t[0].endswith("running_var")), dtype=torch.long, device=dev)
+        for name, off, numel, shape in table1:
             leaf, attr = self._leaf(name)
             leaf.register_buffer(attr, self._view(self.flat_buffers, off, numel, shape))
-            if attr == "running_var":
-                leaf.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long, device=dev))
+            if attr == "running_var":                    # all num_batches_tracked counters are views of ONE int64 vector
+                leaf.register_buffer("num_batches_tracked", self.flat_nbt[len(self._bn_modules)])
                 self._bn_modules.append(leaf)
         self.reset_parameters(seed)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_weights_changed())
@@ -216,8 +218,7 @@ class ResNet50ReID(nn.Module):
         _lib.check(_lib.lib().dali_resnet_forward(plan.h, _lib.stream_ptr(), _lib.ptr(x), int(training), _lib.ptr(emb)),
                    "dali_resnet_forward")
         if training:
-            for m in self._bn_modules:
-                m.num_batches_tracked += 1
+            self.flat_nbt += 1
             self._bwd_plan = plan
         return emb
 

@@ -335,25 +335,39 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WGradArgs a, int tiles
         }
 }
 
-// out[e] (= or +=) sum_s partial[s][e]; fixed order => deterministic.  HBM-bound.
+// out[e] (= or +=) sum_s partial[s][e]; fixed summation tree => deterministic.  HBM-bound.
+// A block covers 256/SL float4 chunks; SL "split lanes" share the slabs of one chunk (s = lane, lane+SL, ...) and are
+// combined through LDS, so tiny outputs with hundreds of slabs (layer1's 64x64 weights) still use many threads.
+template <int SL>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             size_t elems, int splits, int accumulate) {
-    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= elems) return;
-    if (i4 + 3 < elems) {
-        float4 s = *reinterpret_cast<const float4*>(partial + i4);
-        for (int k = 1; k < splits; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * elems + i4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    constexpr int CH = 256 / SL;
+    __shared__ float4 red[256];
+    const int ch = threadIdx.x % CH, sl = threadIdx.x / CH;
+    const size_t i4 = ((size_t)blockIdx.x * CH + ch) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < elems) {
+        if (i4 + 3 < elems) {
+            for (int k = sl; k < splits; k += SL) {
+                const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * elems + i4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        } else {
+            float* sp = reinterpret_cast<float*>(&s);
+            for (int k = sl; k < splits; k += SL)
+                for (size_t e = i4; e < elems; ++e) sp[e - i4] += partial[(size_t)k * elems + e];
         }
-        if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(out + i4); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
-        *reinterpret_cast<float4*>(out + i4) = s;
-    } else {
-        for (size_t e = i4; e < elems; ++e) {
-            float s = partial[e];
-            for (int k = 1; k < splits; ++k) s += partial[(size_t)k * elems + e];
-            out[e] = accumulate ? out[e] + s : s;
+    }
+    if (SL > 1) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sl == 0) {
+            for (int k = 1; k < SL; ++k) { const float4 v = red[k * CH + ch]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
         }
+    }
+    if (sl == 0 && i4 < elems) {
+        const float* sp = reinterpret_cast<const float*>(&s);
+        for (int t = 0; t < 4 && i4 + t < elems; ++t) out[i4 + t] = accumulate ? out[i4 + t] + sp[t] : sp[t];
     }
 }
 
@@ -417,9 +431,10 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     DALI_LAUNCH_CHECK();
-    const size_t elems = (size_t)a.Cm * a.Ntot;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256 + 1)), dim3(256), 0, st, a.partial, out, elems,
-                       a.splits, accumulate);
+    const size_t elems = (size_t)a.Cm * a.Ntot, chunks = (elems + 3) / 4;
+    if (a.splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)((chunks + 15) / 16)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
+    else if (a.splits >= 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((chunks + 63) / 64)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }

@@ -47,8 +47,11 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
 
 // nnops.hip
+constexpr int REDUCE_SMAX = 64;        // rows of the fp64 second-level scratch
+inline size_t reduce_scratch_bytes(int C, int NV) { return (size_t)REDUCE_SMAX * C * NV * sizeof(double); }
 int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
-                       float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd);
+                       float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                       double* scratch);
 int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                           float* scale, float* shift);
 int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,
@@ -57,7 +60,7 @@ int bn_bwd_blocks(int P, int C, int* rows_per_block);
 size_t bn_bwd_partial_floats(int P, int C, bool dual);
 int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
                   float* partial, float* coef_a, float* coef_b, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
-                  uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out);
+                  uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out, double* scratch);
 int launch_stem_pack_image(hipStream_t st, const float* img, int N, int H, int W, uint16_t* out);
 int launch_stem_pack_weight(hipStream_t st, const float* w, int Cout, uint16_t* out);
 int launch_stem_unpack_wgrad(hipStream_t st, const float* padded, int Cout, float* dw);
@@ -65,7 +68,7 @@ int launch_maxpool_bn_fwd(hipStream_t st, const uint16_t* raw, const float* scal
                           uint16_t* out, uint8_t* arg);
 int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg, const uint16_t* raw, const float* mean, const float* invstd,
                           const float* scale, int N, int H, int W, int C, float* partial, float* coef, float* dgamma, float* dbeta,
-                          uint16_t* draw);
+                          uint16_t* draw, double* scratch);
 int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, float* f, int16_t* arg);
 int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, uint16_t* dx);
 int launch_bn1d_fwd(hipStream_t st, const float* x, int N, int C, const float* gamma, const float* beta, float* rm, float* rv, int training,

@@ -25,26 +25,26 @@ __device__ __forceinline__ void load8f(const float* __restrict__ p, float (&f)[8
 // shift = beta - mean*scale; running stats updated as torch does (momentum, unbiased variance).
 // One block per 32 channels: 8 tile-slices x 32 channels, fp64 accumulation.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
+// out[s][col] = sum over rows r = s, s+S, s+2S, ... of in[r][col]  (fp64; fixed order => deterministic).
+// First level of every per-channel reduction: many blocks stream the per-tile partials at HBM speed.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, int rows, int cols, int S, double* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (col >= cols) return;
+    double a = 0.0;
+    for (int r = s; r < rows; r += S) a += (double)in[(size_t)r * cols + col];
+    out[(size_t)s * cols + col] = a;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int tiles, int C, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float momentum, float eps, float* __restrict__ scale,
                                                            float* __restrict__ shift, float* __restrict__ mean_out,
                                                            float* __restrict__ invstd_out) {
-    __shared__ double s1[8][32], s2[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
+    const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
-        for (int t = sl; t < tiles; t += 8) {
-            const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)t * C + c) * 2);
-            a += (double)v.x; b += (double)v.y;
-        }
-    }
-    s1[sl][cl] = a; s2[sl][cl] = b;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        double a = 0.0, b = 0.0;
+        for (int t = 0; t < tiles; ++t) { a += partial[((size_t)t * C + c) * 2]; b += partial[((size_t)t * C + c) * 2 + 1]; }
         const double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -175,24 +175,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
 }
 
 // partial [blocks][C][NV] -> coef [C][3] = (scale, S1/N, S2/N), dgamma = S2, dbeta = S1 (accumulate optional)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C, int NV,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int blocks, int C, int NV,
                                                                int which, double count, const float* __restrict__ scale,
                                                                float* __restrict__ coef, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, const float* __restrict__ invstd_unused) {
-    __shared__ double s1[8][32], s2[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
+    const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
-        for (int t = sl; t < blocks; t += 8) {
-            const float* p = partial + ((size_t)t * C + c) * NV;
-            a += (double)p[0]; b += (double)p[which];
-        }
-    }
-    s1[sl][cl] = a; s2[sl][cl] = b;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        double a = 0.0, b = 0.0;
+        for (int t = 0; t < blocks; ++t) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
         coef[c * 3 + 0] = scale[c];
         coef[c * 3 + 1] = (float)(a / count);
         coef[c * 3 + 2] = (float)(b / count);
@@ -539,9 +529,23 @@ static inline int grid_for(size_t work_items, int cap = 16384) {
 }
 
 // ---- host launchers (shared with the net plan) ----------------------------------------------------
+// two-level: `rows` partial rows of `cols` floats -> S fp64 rows in scratch (S <= REDUCE_SMAX)
+static int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out) {
+    int S = rows / 8;
+    if (S < 1) S = 1;
+    if (S > REDUCE_SMAX) S = REDUCE_SMAX;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256, S), dim3(256), 0, st, partial, rows, cols, S, scratch);
+    DALI_LAUNCH_CHECK();
+    *S_out = S;
+    return DALI_OK;
+}
+
 int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
-                       float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, tiles, C, count, gamma, beta, rm, rv, momentum,
+                       float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                       double* scratch) {
+    int S, rc;
+    if ((rc = reduce_partials(st, partial, tiles, C * 2, scratch, &S))) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, count, gamma, beta, rm, rv, momentum,
                        eps, scale, shift, mean, invstd);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
@@ -573,7 +577,7 @@ int bn_bwd_blocks(int P, int C, int* rows_per_block) {
 }
 int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
                   float* partial, float* coef_a, float* coef_b, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
-                  uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out) {
+                  uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out, double* scratch) {
     int rpb;
     const int blocks = bn_bwd_blocks(P, C, &rpb);
     const int rif = 256 / (C / 8);
@@ -587,11 +591,13 @@ int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, cons
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), lds, st, g, ymask, a, bb, relu, P, C, rpb, partial);
     }
     DALI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, blocks, C, NV, 1, (double)P, a.scale, coef_a,
+    int S, rc;
+    if ((rc = reduce_partials(st, partial, blocks, C * NV, scratch, &S))) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 1, (double)P, a.scale, coef_a,
                        dgamma_a, dbeta_a, (const float*)nullptr);
     DALI_LAUNCH_CHECK();
     if (dual) {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, blocks, C, NV, 2, (double)P, bb.scale, coef_b,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 2, (double)P, bb.scale, coef_b,
                            dgamma_b, dbeta_b, (const float*)nullptr);
         DALI_LAUNCH_CHECK();
     }
@@ -631,7 +637,7 @@ int launch_maxpool_bn_fwd(hipStream_t st, const uint16_t* raw, const float* scal
 }
 int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg, const uint16_t* raw, const float* mean, const float* invstd,
                           const float* scale, int N, int H, int W, int C, float* partial, float* coef, float* dgamma, float* dbeta,
-                          uint16_t* draw) {
+                          uint16_t* draw, double* scratch) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int P = N * H * W;
     int rpb;
@@ -640,7 +646,9 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)rif * C * 2 * sizeof(float), st, dp, arg, raw, mean, invstd,
                        N, H, W, C, Ho, Wo, rpb, partial);
     DALI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, blocks, C, 2, 1, (double)P, scale, coef, dgamma,
+    int S, rc;
+    if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 1, (double)P, scale, coef, dgamma,
                        dbeta, (const float*)nullptr);
     DALI_LAUNCH_CHECK();
     hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 8))), dim3(256), 0, st, dp, arg, raw, mean, invstd, coef, N, H,
@@ -692,8 +700,10 @@ extern "C" int dali_bn_finalize(dali_ctx* ctx, void* stream, const float* partia
                                 float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
     DALI_REQUIRE(ctx && partial && gamma && beta && scale && shift && mean && invstd, "dali_bn_finalize: null argument");
     DALI_REQUIRE(tiles > 0 && C > 0 && count > 0, "dali_bn_finalize: bad sizes");
+    double* scratch = static_cast<double*>(workspace(ctx, reduce_scratch_bytes(C, 2)));
+    if (!scratch) return DALI_ERR_NOMEM;
     return launch_bn_finalize((hipStream_t)stream, partial, tiles, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale,
-                              shift, mean, invstd);
+                              shift, mean, invstd, scratch);
 }
 
 extern "C" int dali_bn_act(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift,
@@ -718,16 +728,17 @@ extern "C" int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const
     const bool dual = raw_b != nullptr;
     DALI_REQUIRE(!dual || (mean_b && invstd_b && scale_b && dgamma_b && dbeta_b && draw_b), "dali_bn_bwd: incomplete second side");
     const size_t pf = bn_bwd_partial_floats((int)pixels, C, dual);
-    const size_t need = align_up(pf * 4, 256) + 2 * align_up((size_t)C * 12, 256);
+    const size_t need = align_up(pf * 4, 256) + 2 * align_up((size_t)C * 12, 256) + reduce_scratch_bytes(C, 3);
     char* ws = static_cast<char*>(workspace(ctx, need));
     if (!ws) return DALI_ERR_NOMEM;
     float* partial = reinterpret_cast<float*>(ws);
     float* coef_a = reinterpret_cast<float*>(ws + align_up(pf * 4, 256));
     float* coef_b = reinterpret_cast<float*>(ws + align_up(pf * 4, 256) + align_up((size_t)C * 12, 256));
+    double* scratch = reinterpret_cast<double*>(ws + align_up(pf * 4, 256) + 2 * align_up((size_t)C * 12, 256));
     BnBwdSide a{raw_a, mean_a, invstd_a, scale_a, shift_a};
     BnBwdSide b{raw_b, mean_b, invstd_b, scale_b, nullptr};
     return launch_bn_bwd((hipStream_t)stream, g, ymask, a, dual ? &b : nullptr, relu, (int)pixels, C, partial, coef_a, coef_b, dgamma_a, dbeta_a,
-                         dgamma_b, dbeta_b, draw_a, draw_b, dz_out);
+                         dgamma_b, dbeta_b, draw_a, draw_b, dz_out, scratch);
 }
 
 extern "C" int dali_maxpool_bn_fwd(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift, int n, int h,
@@ -743,11 +754,12 @@ extern "C" int dali_maxpool_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* 
     DALI_REQUIRE(ctx && dpool && arg && raw && mean && invstd && scale && dgamma && dbeta && draw, "dali_maxpool_bn_bwd: null argument");
     DALI_REQUIRE(C % 8 == 0 && C <= 2048, "dali_maxpool_bn_bwd: C must be a multiple of 8, <= 2048");
     const size_t pf = bn_bwd_partial_floats(n * h * w, C, false);
-    const size_t need = align_up(pf * 4, 256) + align_up((size_t)C * 12, 256);
+    const size_t need = align_up(pf * 4, 256) + align_up((size_t)C * 12, 256) + reduce_scratch_bytes(C, 2);
     char* ws = static_cast<char*>(workspace(ctx, need));
     if (!ws) return DALI_ERR_NOMEM;
     return launch_maxpool_bn_bwd((hipStream_t)stream, dpool, arg, raw, mean, invstd, scale, n, h, w, C, reinterpret_cast<float*>(ws),
-                                 reinterpret_cast<float*>(ws + align_up(pf * 4, 256)), dgamma, dbeta, draw);
+                                 reinterpret_cast<float*>(ws + align_up(pf * 4, 256)), dgamma, dbeta, draw,
+                                 reinterpret_cast<double*>(ws + align_up(pf * 4, 256) + align_up((size_t)C * 12, 256)));
 }
 
 extern "C" int dali_head_pool_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, int n, int hw, int C, float* f, int16_t* arg) {

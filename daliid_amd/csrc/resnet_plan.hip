@@ -38,8 +38,8 @@ struct Block {
     Bn b1, b2, b3, bd;
     bool has_ds;
     int hin, win, hout, wout, cin, width, cout;
-    uint16_t *x, *raw1, *raw2, *raw3, *rawd, *y;
-};
+    uint16_t *x, *raw1, *a1, *raw2, *a2, *raw3, *rawd, *y;    // a = relu(bn(raw)), materialised once (fused
+};                                                              // apply-on-load repeats the VALU work per tap and per M-tile)
 
 struct Arena {
     size_t used = 0;
@@ -66,6 +66,7 @@ struct dali_resnet {
     uint8_t* pool_arg = nullptr;
     float *feat = nullptr, *emb_in = nullptr, *stat_partial = nullptr, *bwd_partial = nullptr, *wgrad_slab = nullptr, *stem_dw_pad = nullptr;
     float *dfeat = nullptr, *neck_mean = nullptr, *neck_invstd = nullptr;
+    double* red_scratch = nullptr;
     int16_t* head_arg = nullptr;
     uint16_t* gbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint16_t* wbf16_flat = nullptr;          // bf16 cast of the whole flat parameter buffer
@@ -214,7 +215,9 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     for (auto& b : net->blocks) {
         const size_t pin = N * b.hin * b.win, pout = N * b.hout * b.wout;
         reserve(net, a, b.raw1, pin * b.width * 2);
+        reserve(net, a, b.a1, pin * b.width * 2);
         reserve(net, a, b.raw2, pout * b.width * 2);
+        reserve(net, a, b.a2, pout * b.width * 2);
         reserve(net, a, b.raw3, pout * b.cout * 2);
         reserve(net, a, b.y, pout * b.cout * 2);
         if (b.has_ds) reserve(net, a, b.rawd, pout * b.cout * 2);
@@ -243,6 +246,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     reserve(net, a, net->bwd_partial, max_bwd_partial);
     reserve(net, a, net->wgrad_slab, max_slab);
     reserve(net, a, net->stem_dw_pad, (size_t)wb * 224 * 4);
+    reserve(net, a, net->red_scratch, reduce_scratch_bytes(net->feat_dim, 3));
     for (int i = 0; i < 6; ++i) reserve(net, a, net->gbuf[i], max_act);
     net->arena_bytes = a.used;
     *out = net;
@@ -328,7 +332,7 @@ int bn_eval(dali_resnet* net, hipStream_t st, Bn& b) {
 }
 int bn_train(dali_resnet* net, hipStream_t st, Bn& b, int tiles, double count) {
     return launch_bn_finalize(st, net->stat_partial, tiles, b.C, count, net->P + b.g_off, net->P + b.b_off, net->B + b.rm_off,
-                              net->B + b.rv_off, 0.1f, 1e-5f, b.scale, b.shift, b.mean, b.invstd);
+                              net->B + b.rv_off, 0.1f, 1e-5f, b.scale, b.shift, b.mean, b.invstd, net->red_scratch);
 }
 
 // conv forward: y(raw) = conv(x [optionally bn+relu on load]); BN of the OUTPUT finalised right after
@@ -399,9 +403,12 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
     const uint16_t* x = net->pool0;
     for (auto& b : net->blocks) {
         b.x = const_cast<uint16_t*>(x);
+        const size_t e1 = (size_t)net->N * b.hin * b.win * b.width, e2 = (size_t)net->N * b.hout * b.wout * b.width;
         if ((rc = conv_bn_fwd(net, st, b.c1, b.b1, x, nullptr, b.raw1, tr))) return rc;
-        if ((rc = conv_bn_fwd(net, st, b.c2, b.b2, b.raw1, &b.b1, b.raw2, tr))) return rc;
-        if ((rc = conv_bn_fwd(net, st, b.c3, b.b3, b.raw2, &b.b2, b.raw3, tr))) return rc;
+        if ((rc = launch_bn_act(st, b.raw1, b.b1.scale, b.b1.shift, nullptr, nullptr, nullptr, nullptr, 1, e1, b.width, b.a1))) return rc;
+        if ((rc = conv_bn_fwd(net, st, b.c2, b.b2, b.a1, nullptr, b.raw2, tr))) return rc;
+        if ((rc = launch_bn_act(st, b.raw2, b.b2.scale, b.b2.shift, nullptr, nullptr, nullptr, nullptr, 1, e2, b.width, b.a2))) return rc;
+        if ((rc = conv_bn_fwd(net, st, b.c3, b.b3, b.a2, nullptr, b.raw3, tr))) return rc;
         const size_t elems = (size_t)net->N * b.hout * b.wout * b.cout;
         if (b.has_ds) {
             if ((rc = conv_bn_fwd(net, st, b.cd, b.bd, x, nullptr, b.rawd, tr))) return rc;
@@ -429,24 +436,24 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     // y = relu(bn3(raw3) + identity): dz = dy*(y>0) written in place over dy
     rc = launch_bn_bwd(st, dy, b.y, s3, b.has_ds ? &sd : nullptr, 1, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
                        net->G + b.b3.g_off, net->G + b.b3.b_off, b.has_ds ? net->G + b.bd.g_off : nullptr, b.has_ds ? net->G + b.bd.b_off : nullptr,
-                       d_raw3, d_rawd, dy);
+                       d_raw3, d_rawd, dy, net->red_scratch);
     if (rc) return rc;
     uint16_t* dz = dy;
     // conv3
-    if ((rc = conv_wgrad(net, st, b.c3, b.raw2, &b.b2, d_raw3))) return rc;
+    if ((rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
     uint16_t* d_a2 = next_gbuf(net, dz, d_raw3, d_rawd);
     if ((rc = conv_dgrad(net, st, b.c3, d_raw3, nullptr, d_a2))) return rc;
-    // bn2 + relu (mask recomputed from raw2), in place
+    // bn2 + relu (mask = a2 > 0), in place
     BnBwdSide s2{b.raw2, b.b2.mean, b.b2.invstd, b.b2.scale, b.b2.shift};
-    if ((rc = launch_bn_bwd(st, d_a2, nullptr, s2, nullptr, 1, Pout, b.width, net->bwd_partial, b.b2.coef, nullptr, net->G + b.b2.g_off,
-                            net->G + b.b2.b_off, nullptr, nullptr, d_a2, nullptr, nullptr))) return rc;
+    if ((rc = launch_bn_bwd(st, d_a2, b.a2, s2, nullptr, 1, Pout, b.width, net->bwd_partial, b.b2.coef, nullptr, net->G + b.b2.g_off,
+                            net->G + b.b2.b_off, nullptr, nullptr, d_a2, nullptr, nullptr, net->red_scratch))) return rc;
     // conv2
-    if ((rc = conv_wgrad(net, st, b.c2, b.raw1, &b.b1, d_a2))) return rc;
+    if ((rc = conv_wgrad(net, st, b.c2, b.a1, nullptr, d_a2))) return rc;
     uint16_t* d_a1 = d_raw3;                                      // d_raw3 is dead now
     if ((rc = conv_dgrad(net, st, b.c2, d_a2, nullptr, d_a1))) return rc;
     BnBwdSide s1{b.raw1, b.b1.mean, b.b1.invstd, b.b1.scale, b.b1.shift};
-    if ((rc = launch_bn_bwd(st, d_a1, nullptr, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
-                            net->G + b.b1.b_off, nullptr, nullptr, d_a1, nullptr, nullptr))) return rc;
+    if ((rc = launch_bn_bwd(st, d_a1, b.a1, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
+                            net->G + b.b1.b_off, nullptr, nullptr, d_a1, nullptr, nullptr, net->red_scratch))) return rc;
     // conv1 (+ identity / downsample branch)
     if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
     uint16_t* dx = d_a2;                                          // d_a2 is dead now
@@ -488,7 +495,7 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
             uint16_t* d_raw0 = next_gbuf(net, net->cur_dy);
             if ((rc = launch_maxpool_bn_bwd(st, net->cur_dy, net->pool_arg, net->raw0, net->stem_bn.mean, net->stem_bn.invstd, net->stem_bn.scale,
                                             net->N, net->stem_h, net->stem_w, net->stem.cout, net->bwd_partial, net->stem_bn.coef,
-                                            net->G + net->stem_bn.g_off, net->G + net->stem_bn.b_off, d_raw0))) return rc;
+                                            net->G + net->stem_bn.g_off, net->G + net->stem_bn.b_off, d_raw0, net->red_scratch))) return rc;
             WGradArgs a{};
             a.dY = d_raw0; a.X = net->ximg; a.partial = net->wgrad_slab; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
             a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w; a.Ntot = 224;

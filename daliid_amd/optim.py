@@ -56,5 +56,4 @@ def ema_update(momentum_net, online_net, beta):
     for m, o in ((momentum_net.flat_params, online_net.flat_params), (momentum_net.flat_buffers, online_net.flat_buffers)):
         _lib.check(L.dali_ema_update(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(m), _lib.ptr(o), m.numel(), float(beta)), "dali_ema_update")
     momentum_net.mark_weights_changed()
-    for bm, bo in zip(momentum_net._bn_modules, online_net._bn_modules):
-        bm.num_batches_tracked.copy_((beta * bm.num_batches_tracked.double() + (1 - beta) * bo.num_batches_tracked.double()).to(torch.long))
+    momentum_net.flat_nbt.copy_((beta * momentum_net.flat_nbt.double() + (1 - beta) * online_net.flat_nbt.double()).to(torch.long))

@@ -1,0 +1,42 @@
+"""Per-layer conv kernel timings at the ResNet-50-ReID shapes (B=256, 256x128) vs a simple roofline."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from daliid_amd import ops_nn as nn
+bf16 = torch.bfloat16
+B = int(os.environ.get("B", "256"))
+# (name, H, W, cin, cout, k, stride, count)
+L = [("l1.c1(first)", 64, 32, 64, 64, 1, 1, 1), ("l1.c1", 64, 32, 256, 64, 1, 1, 2), ("l1.c2", 64, 32, 64, 64, 3, 1, 3), ("l1.c3", 64, 32, 64, 256, 1, 1, 3),
+     ("l1.ds", 64, 32, 64, 256, 1, 1, 1),
+     ("l2.c1(first)", 64, 32, 256, 128, 1, 1, 1), ("l2.c2(s2)", 64, 32, 128, 128, 3, 2, 1), ("l2.c1", 32, 16, 512, 128, 1, 1, 3), ("l2.c2", 32, 16, 128, 128, 3, 1, 3),
+     ("l2.c3", 32, 16, 128, 512, 1, 1, 4), ("l2.ds(s2)", 64, 32, 256, 512, 1, 2, 1),
+     ("l3.c1(first)", 32, 16, 512, 256, 1, 1, 1), ("l3.c2(s2)", 32, 16, 256, 256, 3, 2, 1), ("l3.c1", 16, 8, 1024, 256, 1, 1, 5), ("l3.c2", 16, 8, 256, 256, 3, 1, 5),
+     ("l3.c3", 16, 8, 256, 1024, 1, 1, 6), ("l3.ds(s2)", 32, 16, 512, 1024, 1, 2, 1),
+     ("l4.c1(first)", 16, 8, 1024, 512, 1, 1, 1), ("l4.c1", 16, 8, 2048, 512, 1, 1, 2), ("l4.c2", 16, 8, 512, 512, 3, 1, 3), ("l4.c3", 16, 8, 512, 2048, 1, 1, 3),
+     ("l4.ds", 16, 8, 1024, 2048, 1, 1, 1)]
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+tot = {"fwd": 0, "dgrad": 0, "wgrad": 0, "roof": 0}
+print("%-14s %8s | %9s %9s %9s | %8s %8s  (us; roof = max(flops/2.5PF, bytes/6TB/s) per pass)" % ("layer", "GFLOP", "fwd", "dgrad", "wgrad", "roof", "x cnt"))
+for name, H, W, cin, cout, k, st, cnt in L:
+    pad = k // 2
+    x = torch.randn(B, H, W, cin, device="cuda").to(bf16)
+    w = torch.randn(cout, k, k, cin, device="cuda").to(bf16)
+    wt = torch.randn(cin, k, k, cout, device="cuda").to(bf16)
+    sc = torch.rand(cin, device="cuda") + 0.5; sh = torch.randn(cin, device="cuda")
+    ho, wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    dy = torch.randn(B, ho, wo, cout, device="cuda").to(bf16)
+    fl = 2.0 * B * ho * wo * cout * cin * k * k
+    byt = (x.numel() + dy.numel()) * 2
+    roof = max(fl / 2.5e15, byt / 6e12) * 1e6
+    tf = timeit(lambda: nn.conv2d_fwd(x, w, st, pad, in_scale=sc, in_shift=sh, in_relu=True, want_stats=True))
+    td = timeit(lambda: nn.conv2d_dgrad(dy, wt, (H, W), st, pad))
+    tw = timeit(lambda: nn.conv2d_wgrad(x, dy, (k, k), st, pad, in_scale=sc, in_shift=sh, in_relu=True))
+    print("%-14s %8.1f | %9.1f %9.1f %9.1f | %8.1f x%d   eff fwd %.0f%% dg %.0f%% wg %.0f%%" % (name, fl / 1e9, tf, td, tw, roof, cnt, 100 * roof / tf, 100 * roof / td, 100 * roof / tw))
+    tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt; tot["roof"] += roof * cnt
+print("totals (ms): fwd %.2f dgrad %.2f wgrad %.2f ; roof per pass %.2f" % (tot["fwd"] / 1e3, tot["dgrad"] / 1e3, tot["wgrad"] / 1e3, tot["roof"] / 1e3))

@@ -115,10 +115,10 @@ def test_rank_eval_string_ids_and_known_answer(ops):
 
 def test_validate_pipeline_map_within_1e3(ops):
     """normalise -> distmat -> CMC/mAP end to end on synthetic ids (north star: mAP within 1e-3)."""
-    q, g, qp, gp, qc, gc = E.synthetic_reid_set(60, 20, 3, 64, noise=3.0, seed=12)
+    q, g, qp, gp, qc, gc = E.synthetic_reid_set(60, 20, 3, 64, noise=2.0, seed=12)
     ref_d = E.validate_features(q, g)
     ref_cmc, ref_map = E.eval_market1501(ref_d.numpy(), qp, gp, qc, gc)
-    assert 0.2 < ref_map < 0.999          # a non-trivial ranking problem
+    assert 0.08 < ref_map < 0.999         # a non-trivial ranking problem
     for prec, tol in (("bf16x3", 2e-5), ("bf16", 1e-3)):
         d = ops.pairdist(q.cuda(), g.cuda(), precision=prec, normalize=True)
         cmc, mAP = ops.rank_eval(d, qp, gp, qc, gc)
