@@ -128,23 +128,10 @@ struct WeightLoader {
     }
 };
 
-template <int TM, int TN, bool IN_BN>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
-    using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    int tm, tn;
-    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
-    f32x4_t acc[Cfg::FM][Cfg::FN];
-#pragma unroll
-    for (int i = 0; i < Cfg::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < Cfg::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int K = a.g.R * a.g.S * a.g.Ck;
-    WeightLoader la{a.W, tm * TM, a.Cm, K};
-    PixelLoader<TN, IN_BN> lb;
-    lb.init(a, tn * TN);
-    gemm_mainloop<Cfg>(acc, la, lb, K >> 5, smem);
-
+// Shared epilogue: bf16 store of O (+ residual) and the per-tile BatchNorm partial statistics.
+template <class Cfg>
+__device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)[Cfg::FM][Cfg::FN], int tm, int tn, uint16_t* smem) {
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
     int mb, nb;
     acc_coords<Cfg>(mb, nb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -203,6 +190,145 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
             }
         }
     }
+}
+
+template <int TM, int TN, bool IN_BN>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+    using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    f32x4_t acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int K = a.g.R * a.g.S * a.g.Ck;
+    WeightLoader la{a.W, tm * TM, a.Cm, K};
+    PixelLoader<TN, IN_BN> lb;
+    lb.init(a, tn * TN);
+    gemm_mainloop<Cfg>(acc, la, lb, K >> 5, smem);
+
+    conv_epilogue<Cfg>(a, acc, tm, tn, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad, LDS-DMA version (the one the net plan uses).  Both operand tiles travel HBM/L2 -> LDS with
+// `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write); zero padding comes from the buffer range check:
+// an out-of-image tap is given an offset past num_records and the DMA writes zeros.  The LDS image is the same
+// swizzled [rows][32] bf16 image as gemm_tile.h; because an LDS-DMA wave-instruction writes lane-linear (lane L ->
+// 16-byte slot L of a 1 KiB block = row L>>2, physical chunk L&3), the XOR swizzle is applied to the SOURCE chunk
+// each lane fetches.  Two LDS stages, one barrier per k-tile: the DMA of tile t+1 is in flight while tile t is
+// multiplied.  Tap / channel position advance as wave-uniform scalars (no per-load division).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+constexpr uint32_t DMA_OOB = 0x7ffffff0u;
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+    using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
+    constexpr int FM = Cfg::FM, FN = Cfg::FN;
+    constexpr int A_BLK = TM / 16 / 4, B_BLK = TN / 16 / 4;      // 1 KiB DMA blocks (16 rows x 64 B) per wave per k-tile
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const GatherGeom g = a.g;
+    const int K = g.R * g.S * g.Ck;
+    const int ktiles = K >> 5;
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+
+    // lane-constant part of the source swizzle: LDS slot `lane` of a block = row lane>>2, physical chunk lane&3
+    const int r_in = lane >> 2;
+    const int kc = (lane & 3) ^ lds_swz(r_in);                     // logical 16-byte chunk this lane fetches
+    // A (weights): rows m0 + 16*(wave + 4*i) + r_in
+    uint32_t a_off[A_BLK];
+#pragma unroll
+    for (int i = 0; i < A_BLK; ++i) {
+        const int m = tm * TM + 16 * (wave + 4 * i) + r_in;
+        a_off[i] = (m < a.Cm) ? (uint32_t)(m * K + kc * 8) * 2u : DMA_OOB;
+    }
+    // B (pixels): rows p0 + 16*(wave + 4*i) + r_in
+    int b_pix[B_BLK], b_h0[B_BLK], b_w0[B_BLK];
+#pragma unroll
+    for (int i = 0; i < B_BLK; ++i) {
+        const int p = tn * TN + 16 * (wave + 4 * i) + r_in;
+        int n = 0, ho = 0, wo = 0;
+        const bool ok = p < a.P;
+        if (ok) decode_pixel(g, p, n, ho, wo);
+        if (g.mode == 0) { b_h0[i] = ho * g.stride - g.pad; b_w0[i] = wo * g.stride - g.pad; }
+        else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
+        if (!ok) b_h0[i] = -0x40000000;                             // never in range
+        b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;      // element offset of the image (+ this lane's chunk)
+    }
+
+    // wave-uniform k position
+    int kr = 0, ks = 0, kc0 = 0;
+    auto issue = [&](int stage) {
+        uint16_t* sa = smem + stage * Cfg::STAGE_ELEMS;
+        uint16_t* sb = sa + Cfg::A_ELEMS;
+        const int kbase = ((kr * g.S + ks) * g.Ck + kc0) * 2;      // byte offset of this k-tile inside a weight row
+#pragma unroll
+        for (int i = 0; i < A_BLK; ++i) {
+            const uint32_t off = (a_off[i] == DMA_OOB) ? DMA_OOB : a_off[i] + (uint32_t)kbase;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (wave + 4 * i) * 512), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_BLK; ++i) {
+            int hi, wi;
+            bool ok;
+            if (g.mode == 0) {
+                hi = b_h0[i] + kr; wi = b_w0[i] + ks;
+                ok = true;
+            } else {
+                const int th = b_h0[i] - kr, tw = b_w0[i] - ks;
+                ok = (th >= 0) && (tw >= 0);
+                if (g.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                else { hi = th; wi = tw; }
+            }
+            ok = ok && ((unsigned)hi < (unsigned)g.Hin) && ((unsigned)wi < (unsigned)g.Win);
+            const uint32_t off = ok ? (uint32_t)(b_pix[i] + hi * g.row_pitch + wi * g.pix_pitch + kc0) * 2u : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + 4 * i) * 512), 16, off, 0, 0, 0);
+        }
+        // advance (channel block fastest, then s, then r)
+        kc0 += 32;
+        if (kc0 == g.Ck) { kc0 = 0; if (++ks == g.S) { ks = 0; ++kr; } }
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frag_off = (lane & 15) * 32 + (((lane >> 4) ^ lds_swz(lane & 15)) << 3);
+    const int a_row0 = wm * (TM / 2), b_row0 = wn * (TN / 2);
+
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        if (kt + 1 < ktiles) issue((kt + 1) & 1);
+        const uint16_t* sa = smem + (kt & 1) * Cfg::STAGE_ELEMS;
+        const uint16_t* sb = sa + Cfg::A_ELEMS;
+        bf16x8_t fa[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + (a_row0 + i * 16) * 32 + frag_off);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(sb + (b_row0 + j * 16) * 32 + frag_off);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    conv_epilogue<Cfg>(a, acc, tm, tn, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,6 +461,102 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WGradArgs a, int tiles
         }
 }
 
+// wgrad, LDS-DMA version (the one the net plan uses): same tile / fragment scheme as igemm_wgrad_kernel, operands
+// streamed by `buffer_load_dwordx4 ... lds` (1 KiB block = 4 pixel rows x 256 B), swizzle applied on the source chunk.
+__global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+    constexpr int TILE = 32 * 128;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = tiles_m * tiles_n;
+    const int tile = blockIdx.x % tiles, ks = blockIdx.x / tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const GatherGeom g = a.g;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+
+    // lane-constant source chunk: slot lane&15 of row (4*block + lane>>4); swz(row) is the same for blocks w and w+4
+    const int r_in = lane >> 4, ps = lane & 15;
+    const int c16 = ((((ps >> 1) ^ wg_swz(4 * wave + r_in)) << 1) | (ps & 1));
+    const int am = m0 + c16 * 8;
+    const bool a_ok = am < a.Cm;
+    const int bn = n0 + c16 * 8;
+    const bool b_ok = bn < a.Ntot;
+    const int tap = b_ok ? bn / g.Ck : 0;
+    const int ci = bn - tap * g.Ck;
+    const int r = tap / g.S, s = tap - r * g.S;
+
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.P, p_begin + a.pix_per_split);
+    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+
+    auto issue = [&](int kt, int stage) {
+        uint16_t* sa = smem + stage * 2 * TILE;
+        uint16_t* sb = sa + TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = wave + 4 * i;
+            const int p = p_begin + kt * 32 + 4 * blk + r_in;
+            uint32_t oa = DMA_OOB, ob = DMA_OOB;
+            if (p < p_end) {
+                if (a_ok) oa = (uint32_t)(p * a.Cm + am) * 2u;
+                if (b_ok) {
+                    int n, ho, wo;
+                    decode_pixel(g, p, n, ho, wo);
+                    const int hi = ho * g.stride - g.pad + r, wi = wo * g.stride - g.pad + s;
+                    if ((unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win)
+                        ob = (uint32_t)((int)((long long)n * g.img_pitch) + hi * g.row_pitch + wi * g.pix_pitch + ci) * 2u;
+                }
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)(sa + blk * 512), 16, oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + blk * 512), 16, ob, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (ksteps > 0) {
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < ksteps; ++kt) {
+            if (kt + 1 < ksteps) issue(kt + 1, (kt + 1) & 1);
+            const uint16_t* sa = smem + (kt & 1) * 2 * TILE;
+            const uint16_t* sb = sa + TILE;
+            bf16x8_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, wm * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t fb = tr_frag(sb, wn * 4 + j, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
+                if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
+            }
+        }
+}
+
 // out[e] (= or +=) sum_s partial[s][e]; fixed summation tree => deterministic.  HBM-bound.
 // A block covers 256/SL float4 chunks; SL "split lanes" share the slabs of one chunk (s = lane, lane+SL, ...) and are
 // combined through LDS, so tiny outputs with hundreds of slabs (layer1's 64x64 weights) still use many threads.
@@ -391,17 +613,22 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     IGemmArgs args = a;
     args.g.lw = ilog2_exact(a.g.Wout);
     args.g.lhw = ilog2_exact(a.g.Hout * a.g.Wout);
+    // the LDS-DMA kernel addresses both tensors with 32-bit byte offsets through buffer descriptors
+    const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
+    const bool dma_ok = !in_bn && x_bytes < 0x7ff00000ll && (long long)a.Cm * a.g.R * a.g.S * a.g.Ck * 2 < 0x7ff00000ll;
     if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<64, 256, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<64, 256, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
     } else {
         using Cfg = GemmCfg<128, 128, 1, 1, 1>;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<128, 128, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
     }
     DALI_LAUNCH_CHECK();
@@ -428,7 +655,10 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     args.g.lhw = ilog2_exact(a.g.Hout * a.g.Wout);
     const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.Ntot + 127) / 128;
     const int grid = tiles_m * tiles_n * a.splits;
+    const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
+    const bool dma_ok = x_bytes < 0x7ff00000ll && (long long)a.P * a.Cm * 2 < 0x7ff00000ll;
     if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
+    else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     DALI_LAUNCH_CHECK();
     const size_t elems = (size_t)a.Cm * a.Ntot, chunks = (elems + 3) / 4;

@@ -30,9 +30,16 @@ __device__ __forceinline__ void load8f(const float* __restrict__ p, float (&f)[8
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, int rows, int cols, int S, double* __restrict__ out) {
     const int col = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
     if (col >= cols) return;
-    double a = 0.0;
-    for (int r = s; r < rows; r += S) a += (double)in[(size_t)r * cols + col];
-    out[(size_t)s * cols + col] = a;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // 4 independent chains keep 4+ loads in flight
+    int r = s;
+    for (; r + 3 * S < rows; r += 4 * S) {
+        a0 += (double)in[(size_t)r * cols + col];
+        a1 += (double)in[(size_t)(r + S) * cols + col];
+        a2 += (double)in[(size_t)(r + 2 * S) * cols + col];
+        a3 += (double)in[(size_t)(r + 3 * S) * cols + col];
+    }
+    for (; r < rows; r += S) a0 += (double)in[(size_t)r * cols + col];
+    out[(size_t)s * cols + col] = (a0 + a1) + (a2 + a3);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int tiles, int C, double count,
@@ -44,7 +51,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
         double a = 0.0, b = 0.0;
-        for (int t = 0; t < tiles; ++t) { a += partial[((size_t)t * C + c) * 2]; b += partial[((size_t)t * C + c) * 2 + 1]; }
+#pragma unroll 8
+        for (int t = 0; t < tiles; ++t) {
+            const double2 v = *reinterpret_cast<const double2*>(partial + ((size_t)t * C + c) * 2);
+            a += v.x; b += v.y;
+        }
         const double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
         double a = 0.0, b = 0.0;
+#pragma unroll 8
         for (int t = 0; t < blocks; ++t) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
         coef[c * 3 + 0] = scale[c];
         coef[c * 3 + 1] = (float)(a / count);
@@ -531,9 +543,9 @@ static inline int grid_for(size_t work_items, int cap = 16384) {
 // ---- host launchers (shared with the net plan) ----------------------------------------------------
 // two-level: `rows` partial rows of `cols` floats -> S fp64 rows in scratch (S <= REDUCE_SMAX)
 static int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out) {
-    int S = rows / 8;
+    int S = rows / 16;                          // >= 16 rows per first-level thread; second level loops S <= 16
     if (S < 1) S = 1;
-    if (S > REDUCE_SMAX) S = REDUCE_SMAX;
+    if (S > 16) S = 16;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256, S), dim3(256), 0, st, partial, rows, cols, S, scratch);
     DALI_LAUNCH_CHECK();
     *S_out = S;

@@ -34,9 +34,9 @@ for name, H, W, cin, cout, k, st, cnt in L:
     fl = 2.0 * B * ho * wo * cout * cin * k * k
     byt = (x.numel() + dy.numel()) * 2
     roof = max(fl / 2.5e15, byt / 6e12) * 1e6
-    tf = timeit(lambda: nn.conv2d_fwd(x, w, st, pad, in_scale=sc, in_shift=sh, in_relu=True, want_stats=True))
+    tf = timeit(lambda: nn.conv2d_fwd(x, w, st, pad, want_stats=True))
     td = timeit(lambda: nn.conv2d_dgrad(dy, wt, (H, W), st, pad))
-    tw = timeit(lambda: nn.conv2d_wgrad(x, dy, (k, k), st, pad, in_scale=sc, in_shift=sh, in_relu=True))
+    tw = timeit(lambda: nn.conv2d_wgrad(x, dy, (k, k), st, pad))
     print("%-14s %8.1f | %9.1f %9.1f %9.1f | %8.1f x%d   eff fwd %.0f%% dg %.0f%% wg %.0f%%" % (name, fl / 1e9, tf, td, tw, roof, cnt, 100 * roof / tf, 100 * roof / td, 100 * roof / tw))
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt; tot["roof"] += roof * cnt
 print("totals (ms): fwd %.2f dgrad %.2f wgrad %.2f ; roof per pass %.2f" % (tot["fwd"] / 1e3, tot["dgrad"] / 1e3, tot["wgrad"] / 1e3, tot["roof"] / 1e3))
