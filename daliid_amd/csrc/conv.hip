@@ -662,7 +662,8 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     DALI_LAUNCH_CHECK();
     const size_t elems = (size_t)a.Cm * a.Ntot, chunks = (elems + 3) / 4;
-    if (a.splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)((chunks + 15) / 16)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
+    if (a.splits >= 128) hipLaunchKernelGGL(splitk_reduce_kernel<64>, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
+    else if (a.splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)((chunks + 15) / 16)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
     else if (a.splits >= 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((chunks + 63) / 64)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
     else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
     DALI_LAUNCH_CHECK();
@@ -725,7 +726,7 @@ extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
     a.Cm = cout; a.P = n * ho * wo; a.Ntot = r * s * cin;
     fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
     size_t ws_bytes;
-    wgrad_plan(a.Cm, a.Ntot, a.P, 1024, &a.splits, &a.pix_per_split, &ws_bytes);
+    wgrad_plan(a.Cm, a.Ntot, a.P, 768, &a.splits, &a.pix_per_split, &ws_bytes);
     a.partial = static_cast<float*>(workspace(ctx, ws_bytes));
     if (!a.partial) return DALI_ERR_NOMEM;
     return launch_igemm_wgrad((hipStream_t)stream, a, dw, accumulate);

@@ -178,28 +178,38 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* __restrict
     __shared__ float s_d[RANK_PMAX];
     __shared__ int s_i[RANK_PMAX];
     __shared__ int s_cnt[RANK_PMAX + 1];
-    __shared__ int s_n;
+    __shared__ int s_junk[RANK_PMAX];
+    __shared__ int s_n, s_nj;
     __shared__ float s_red[4];
     __shared__ int s_scan[256];
     const int q = blockIdx.x, tid = threadIdx.x;
     const float* drow = distmat + (size_t)q * ng;
     const int qp = q_pids[q], qc = q_cams[q];
-    if (tid == 0) s_n = 0;
+    if (tid == 0) { s_n = 0; s_nj = 0; }
     __syncthreads();
-    // 1. collect matches
-    for (int g = tid; g < ng; g += 256) {
-        if (g_pids[g] == qp && g_cams[g] != qc) {
-            const int slot = atomicAdd(&s_n, 1);
-            if (slot < RANK_PMAX) { s_d[slot] = drow[g]; s_i[slot] = g; }
+    // 1. collect matches (same pid, other camera) and junk (same pid, same camera); ids are L2-resident
+    const bool vec = (ng & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_pids) | reinterpret_cast<uintptr_t>(drow)) & 15) == 0;
+    auto visit_pid = [&](int g, int pid) {
+        if (pid == qp) {
+            if (g_cams[g] != qc) { const int slot = atomicAdd(&s_n, 1); if (slot < RANK_PMAX) { s_d[slot] = drow[g]; s_i[slot] = g; } }
+            else { const int slot = atomicAdd(&s_nj, 1); if (slot < RANK_PMAX) s_junk[slot] = g; }
         }
+    };
+    if (vec) {
+        for (int g = tid * 4; g < ng; g += 1024) {
+            const int4 p = *reinterpret_cast<const int4*>(g_pids + g);
+            visit_pid(g, p.x); visit_pid(g + 1, p.y); visit_pid(g + 2, p.z); visit_pid(g + 3, p.w);
+        }
+    } else {
+        for (int g = tid; g < ng; g += 256) visit_pid(g, g_pids[g]);
     }
     __syncthreads();
-    const int np = s_n;
+    const int np = s_n, nj = s_nj;
     if (np == 0) {
         if (tid == 0) { ap_out[q] = 0.f; first_rank[q] = -1; }
         return;
     }
-    if (np > RANK_PMAX) {
+    if (np > RANK_PMAX || nj > RANK_PMAX) {
         if (tid == 0) { atomicMax(status, 1); ap_out[q] = 0.f; first_rank[q] = -1; }
         return;
     }
@@ -224,20 +234,40 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* __restrict
             __syncthreads();
         }
     }
-    // 3. bin every kept gallery entry
+    // 3. bin EVERY gallery entry by the number of matches with a smaller key (only the distance row is read:
+    //    4 bytes per pair, coalesced 16 B per lane), then take the junk entries back out of their bins.
     const float last_d = s_d[np - 1];
     const int last_i = s_i[np - 1];
-    for (int g = tid; g < ng; g += 256) {
-        const float d = drow[g];
-        if (g_pids[g] == qp && g_cams[g] == qc) continue;          // junk
-        if (key_less(last_d, last_i, d, g)) continue;                 // beyond the last match: affects no position
-        int lo = 0, hi = np;                                          // lower bound: #matches with key < (d,g)
+    auto bin = [&](float d, int g, int delta) {
+        if (key_less(last_d, last_i, d, g)) return;                   // beyond the last match: affects no position
+        int lo = 0, hi = np;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (key_less(s_d[mid], s_i[mid], d, g)) lo = mid + 1; else hi = mid;
         }
-        atomicAdd(&s_cnt[lo], 1);
+        atomicAdd(&s_cnt[lo], delta);
+    };
+    if (vec) {
+        int g = tid * 4;
+        for (; g + 3072 < ng; g += 4096) {                            // 4 independent 16-byte loads in flight
+            const float4 v0 = *reinterpret_cast<const float4*>(drow + g);
+            const float4 v1 = *reinterpret_cast<const float4*>(drow + g + 1024);
+            const float4 v2 = *reinterpret_cast<const float4*>(drow + g + 2048);
+            const float4 v3 = *reinterpret_cast<const float4*>(drow + g + 3072);
+            bin(v0.x, g, 1); bin(v0.y, g + 1, 1); bin(v0.z, g + 2, 1); bin(v0.w, g + 3, 1);
+            bin(v1.x, g + 1024, 1); bin(v1.y, g + 1025, 1); bin(v1.z, g + 1026, 1); bin(v1.w, g + 1027, 1);
+            bin(v2.x, g + 2048, 1); bin(v2.y, g + 2049, 1); bin(v2.z, g + 2050, 1); bin(v2.w, g + 2051, 1);
+            bin(v3.x, g + 3072, 1); bin(v3.y, g + 3073, 1); bin(v3.z, g + 3074, 1); bin(v3.w, g + 3075, 1);
+        }
+        for (; g < ng; g += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(drow + g);
+            bin(v.x, g, 1); bin(v.y, g + 1, 1); bin(v.z, g + 2, 1); bin(v.w, g + 3, 1);
+        }
+    } else {
+        for (int g = tid; g < ng; g += 256) bin(drow[g], g, 1);
     }
+    __syncthreads();
+    for (int t = tid; t < nj; t += 256) bin(drow[s_junk[t]], s_junk[t], -1);
     __syncthreads();
     // 4. inclusive scan of the bins + AP (sequential chunks of 256)
     float ap_part = 0.f;

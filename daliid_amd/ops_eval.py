@@ -81,32 +81,36 @@ def factorize_ids(*arrays):
     return out
 
 
-def rank_eval(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, return_per_query=False):
-    """market1501 CMC/mAP of torchreid.metrics.evaluate_rank (validateModels.py:68) on the GPU.
-    distmat: CUDA fp32 [nq,ng].  Returns (cmc numpy float32 [max_rank], mAP float)."""
+def rank_eval_codes(distmat, qp, gp, qc, gc, max_rank=50):
+    """Device-side part of rank_eval: ids already int32 codes on the GPU.  -> dict of device tensors (no host sync)."""
     nq, ng = distmat.shape
     dev = distmat.device
     max_rank = min(max_rank, ng)
+    out = dict(cmc=torch.empty(max_rank, device=dev, dtype=torch.float32), mAP=torch.empty(1, device=dev, dtype=torch.float32),
+               map64=torch.empty(1, device=dev, dtype=torch.float64), nvalid=torch.empty(1, device=dev, dtype=torch.int32),
+               status=torch.empty(1, device=dev, dtype=torch.int32), ap=torch.empty(nq, device=dev, dtype=torch.float32),
+               first_rank=torch.empty(nq, device=dev, dtype=torch.int32))
+    _lib.check(_lib.lib().dali_rank_eval(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(distmat, torch.float32, "distmat"),
+                                          _lib.ptr(qp, torch.int32), _lib.ptr(gp, torch.int32), _lib.ptr(qc, torch.int32), _lib.ptr(gc, torch.int32),
+                                          nq, ng, max_rank, _lib.ptr(out["cmc"]), _lib.ptr(out["mAP"]), _lib.ptr(out["map64"]),
+                                          _lib.ptr(out["nvalid"]), _lib.ptr(out["ap"]), _lib.ptr(out["first_rank"]), _lib.ptr(out["status"])),
+               "dali_rank_eval")
+    return out
+
+
+def rank_eval(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, return_per_query=False):
+    """market1501 CMC/mAP of torchreid.metrics.evaluate_rank (validateModels.py:68) on the GPU.
+    distmat: CUDA fp32 [nq,ng].  Returns (cmc numpy float32 [max_rank], mAP float)."""
+    dev = distmat.device
     qp, gp = factorize_ids(q_pids, g_pids)
     qc, gc = factorize_ids(q_camids, g_camids)
     t = lambda a: torch.from_numpy(a).to(dev)
-    qp, gp, qc, gc = t(qp), t(gp), t(qc), t(gc)
-    cmc = torch.empty(max_rank, device=dev, dtype=torch.float32)
-    mAP = torch.empty(1, device=dev, dtype=torch.float32)
-    map64 = torch.empty(1, device=dev, dtype=torch.float64)
-    nvalid = torch.empty(1, device=dev, dtype=torch.int32)
-    status = torch.empty(1, device=dev, dtype=torch.int32)
-    ap = torch.empty(nq, device=dev, dtype=torch.float32)
-    fr = torch.empty(nq, device=dev, dtype=torch.int32)
-    _lib.check(_lib.lib().dali_rank_eval(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(distmat, torch.float32, "distmat"),
-                                          _lib.ptr(qp), _lib.ptr(gp), _lib.ptr(qc), _lib.ptr(gc), nq, ng, max_rank,
-                                          _lib.ptr(cmc), _lib.ptr(mAP), _lib.ptr(map64), _lib.ptr(nvalid), _lib.ptr(ap),
-                                          _lib.ptr(fr), _lib.ptr(status)), "dali_rank_eval")
-    if int(status.item()) != 0:
-        raise _lib.DaliError("dali_rank_eval: a query has more than 4096 matches (documented limit)")
-    if int(nvalid.item()) == 0:
+    o = rank_eval_codes(distmat, t(qp), t(gp), t(qc), t(gc), max_rank)
+    if int(o["status"].item()) != 0:
+        raise _lib.DaliError("dali_rank_eval: a query has more than 4096 matches or junk entries (documented limit)")
+    if int(o["nvalid"].item()) == 0:
         raise AssertionError("Error: all query identities do not appear in gallery")
-    res = (cmc.cpu().numpy(), float(map64.item()))
+    res = (o["cmc"].cpu().numpy(), float(o["map64"].item()))
     if return_per_query:
-        return res + (ap.cpu().numpy(), fr.cpu().numpy())
+        return res + (o["ap"].cpu().numpy(), o["first_rank"].cpu().numpy())
     return res
