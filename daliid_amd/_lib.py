@@ -49,6 +49,16 @@ _SIGNATURES = {
     "dali_bn1d_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                       c_void_p, c_void_p, c_void_p],
     "dali_bn1d_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6,
+    "dali_linear_fwd": [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int] * 3,
+    "dali_linear_dgrad": [c_void_p] * 7 + [c_int] * 3,
+    "dali_linear_wgrad": [c_void_p] * 6 + [c_int] * 3,
+    "dali_vit_patchify": [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
+    "dali_vit_assemble_tokens": [c_void_p] * 5 + [c_int] * 3 + [c_void_p],
+    "dali_vit_assemble_tokens_bwd": [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 3,
+    "dali_layernorm_fwd": [c_void_p] * 5 + [c_int, c_int, c_float] + [c_void_p] * 3,
+    "dali_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int] + [c_void_p] * 3,
+    "dali_attention_fwd": [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p, c_void_p],
+    "dali_attention_bwd": [c_void_p] * 6 + [c_int] * 4 + [c_float, c_void_p],
     "dali_center_loss_fwd": [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_void_p],
     "dali_center_loss_bwd": [c_void_p] * 6 + [c_float, c_int, c_int, c_void_p, c_float, c_void_p],
     "dali_proxy_loss_fwd": [c_void_p] * 6 + [c_float, c_int, c_int] + [c_void_p] * 5,

@@ -145,6 +145,23 @@ __device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)
             if (p < a.P && c < a.Cm) {      // Cm is a multiple of 4: the 4 channels are all valid
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const size_t o = (size_t)p * a.Cm + c;
+                if (a.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (a.O2) *reinterpret_cast<uint2*>(a.O2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                if (a.act == 1) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = 0.5f * v[t] * (1.0f + erff(v[t] * 0.70710678118654752f));
+                }
+                if (a.dact_pre) {
+                    const uint2 pv = *reinterpret_cast<const uint2*>(a.dact_pre + o);
+                    const float x4[4] = {bf16_bits_to_f32(pv.x & 0xffffu), bf16_bits_to_f32(pv.x >> 16), bf16_bits_to_f32(pv.y & 0xffffu),
+                                         bf16_bits_to_f32(pv.y >> 16)};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        v[t] *= 0.5f * (1.0f + erff(x4[t] * 0.70710678118654752f)) + x4[t] * 0.3989422804014327f * expf(-0.5f * x4[t] * x4[t]);
+                }
                 if (a.Res) {
                     const uint2 rv = *reinterpret_cast<const uint2*>(a.Res + o);
                     v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
@@ -730,4 +747,62 @@ extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
     a.partial = static_cast<float*>(workspace(ctx, ws_bytes));
     if (!a.partial) return DALI_ERR_NOMEM;
     return launch_igemm_wgrad((hipStream_t)stream, a, dw, accumulate);
+}
+
+// ---- Linear layers (ViT: qkv / proj / fc1 / fc2 / patch embedding) on the same engine: a Linear is a 1x1 conv over tokens ----
+static void linear_geom(GatherGeom& g, int K) {
+    g.Hout = 1; g.Wout = 1; g.Hin = 1; g.Win = 1; g.Ck = K; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.mode = 0;
+    g.pix_pitch = K; g.row_pitch = K; g.img_pitch = K; g.lw = g.lhw = -1;
+}
+namespace dali {
+int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,
+                      uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N) {
+    IGemmArgs a{};
+    a.W = w; a.X = x; a.O = y; a.Res = residual; a.bias = bias; a.act = act; a.O2 = pre; a.dact_pre = dact_pre;
+    a.Cm = N; a.P = rows;
+    linear_geom(a.g, K);
+    return launch_igemm_conv(st, a);
+}
+int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab) {
+    WGradArgs a{};
+    a.dY = dy; a.X = x; a.partial = slab; a.Cm = N; a.P = rows; a.Ntot = K;
+    linear_geom(a.g, K);
+    size_t wsb;
+    wgrad_plan(a.Cm, a.Ntot, a.P, 768, &a.splits, &a.pix_per_split, &wsb);
+    return launch_igemm_wgrad(st, a, dw, 0);
+}
+size_t linear_wgrad_slab_bytes(int rows, int K, int N) {
+    int sp, pps; size_t wsb;
+    wgrad_plan(N, K, rows, 768, &sp, &pps, &wsb);
+    return wsb;
+}
+}  // namespace dali
+
+/* y[rows,N] = act(x[rows,K] @ w[N,K]^T + bias) (+ residual);  pre (nullable) receives the pre-activation. */
+extern "C" int dali_linear_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, const float* bias, int act,
+                               const uint16_t* residual, uint16_t* y, uint16_t* pre, int rows, int K, int N) {
+    DALI_REQUIRE(ctx && x && w && y, "dali_linear_fwd: null argument");
+    DALI_REQUIRE(K % 32 == 0 && N % 4 == 0 && rows > 0, "dali_linear_fwd: K must be a multiple of 32 and N of 4 (K=%d N=%d)", K, N);
+    DALI_REQUIRE(act == 0 || act == 1, "dali_linear_fwd: act must be 0 (none) or 1 (gelu)");
+    return launch_linear_fwd((hipStream_t)stream, x, w, bias, act, residual, y, pre, nullptr, rows, K, N);
+}
+/* dx[rows,K] = (dy[rows,N] @ wt[K,N]^T) * gelu'(gelu_pre) (+ residual);  wt is the transposed weight image [K][N]. */
+extern "C" int dali_linear_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, const uint16_t* gelu_pre,
+                                 const uint16_t* residual, uint16_t* dx, int rows, int K, int N) {
+    DALI_REQUIRE(ctx && dy && wt && dx, "dali_linear_dgrad: null argument");
+    DALI_REQUIRE(N % 32 == 0 && K % 4 == 0 && rows > 0, "dali_linear_dgrad: N must be a multiple of 32 and K of 4 (K=%d N=%d)", K, N);
+    return launch_linear_fwd((hipStream_t)stream, dy, wt, nullptr, 0, residual, dx, nullptr, gelu_pre, rows, N, K);
+}
+/* dw[N,K] (fp32) = dy^T @ x;  dbias[N] (nullable, fp32) = column sums of dy. */
+extern "C" int dali_linear_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, int rows,
+                                 int K, int N) {
+    DALI_REQUIRE(ctx && x && dy && dw, "dali_linear_wgrad: null argument");
+    DALI_REQUIRE(K % 8 == 0 && N % 8 == 0 && rows > 0, "dali_linear_wgrad: K and N must be multiples of 8");
+    const size_t slab = align_up(linear_wgrad_slab_bytes(rows, K, N), 256);
+    const size_t part = align_up(colsum_partial_floats(rows, N) * 4, 256);
+    char* ws = static_cast<char*>(workspace(ctx, slab + part + reduce_scratch_bytes(N, 1)));
+    if (!ws) return DALI_ERR_NOMEM;
+    int rc = launch_linear_wgrad((hipStream_t)stream, x, dy, dw, rows, K, N, reinterpret_cast<float*>(ws));
+    if (rc || !dbias) return rc;
+    return launch_colsum((hipStream_t)stream, dy, rows, N, dbias, reinterpret_cast<float*>(ws + slab), reinterpret_cast<double*>(ws + slab + part));
 }

@@ -23,6 +23,10 @@ struct IGemmArgs {
     const float* in_scale;    // optional [Ck] affine (+ReLU) applied to X on load
     const float* in_shift;
     float* stats;             // optional [tiles_n][Cm][2] partial sum / sumsq of the fp32 results
+    const float* bias;        // optional [Cm] added before the activation (linear layers)
+    uint16_t* O2;             // optional second output: the value BEFORE the activation (kept for the backward)
+    const uint16_t* dact_pre; // optional [P][Cm]: multiply the result by gelu'(dact_pre) (backward through GELU)
+    int act;                  // 0 none, 1 exact-erf GELU (vit_pytorch.py:120-136 nn.GELU)
     int Cm, P, in_relu;
     GatherGeom g;
 };
@@ -46,9 +50,16 @@ int igemm_conv_stat_tiles(int Cm, int P);
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes);
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
 
+int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,
+                      uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N);
+int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab);
+size_t linear_wgrad_slab_bytes(int rows, int K, int N);
+
 // nnops.hip
 constexpr int REDUCE_SMAX = 64;        // rows of the fp64 second-level scratch
 inline size_t reduce_scratch_bytes(int C, int NV) { return (size_t)REDUCE_SMAX * C * NV * sizeof(double); }
+// two-level fp64 sum of `rows` partial rows of `cols` floats: scratch[S][cols] (S <= 16 returned through S_out)
+int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out);
 int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                        float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                        double* scratch);
@@ -77,5 +88,21 @@ int launch_bn1d_bwd(hipStream_t st, const float* x, const float* dy, int N, int 
                     float* dx, float* dgamma, float* dbeta);
 int launch_cast_bf16(hipStream_t st, const float* x, size_t n, uint16_t* y);
 int launch_weight_transpose(hipStream_t st, const uint16_t* w, int Co, int T, int Ci, uint16_t* wt);
+
+
+// vit_ops.hip
+int launch_patchify(hipStream_t st, const float* img, int B, int H, int W, int ps, int stride, uint16_t* out);
+int launch_assemble_tokens(hipStream_t st, const uint16_t* pe, const float* cls, const float* pos, int B, int T, int C, uint16_t* x);
+int launch_assemble_tokens_bwd(hipStream_t st, const uint16_t* dx, int B, int T, int C, float* dpos, float* dcls, uint16_t* dpe);
+int launch_layernorm_fwd(hipStream_t st, const uint16_t* x, const float* gamma, const float* beta, int rows, int C, float eps,
+                         uint16_t* y, float* mean, float* rstd);
+size_t layernorm_bwd_partial_floats(int rows, int C);
+int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean, const float* rstd,
+                         const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta, float* partial, double* scratch);
+size_t colsum_partial_floats(int rows, int C);
+int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out, float* partial, double* scratch);
+int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse);
+int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
+                         float scale, uint16_t* dqkv);
 
 }  // namespace dali

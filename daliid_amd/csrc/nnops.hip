@@ -542,7 +542,7 @@ static inline int grid_for(size_t work_items, int cap = 16384) {
 
 // ---- host launchers (shared with the net plan) ----------------------------------------------------
 // two-level: `rows` partial rows of `cols` floats -> S fp64 rows in scratch (S <= REDUCE_SMAX)
-static int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out) {
+int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out) {
     int S = rows / 16;                          // >= 16 rows per first-level thread; second level loops S <= 16
     if (S < 1) S = 1;
     if (S > 16) S = 16;

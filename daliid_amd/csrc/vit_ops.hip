@@ -1,0 +1,619 @@
+// vit_ops.hip -- kernels of the TransReID ViT encoder (vit_pytorch.py:120-184, 251-288, 375-408) that are not plain
+// linear layers: patch extraction, token assembly (cls + pos_embed), LayerNorm, multi-head self-attention
+// (softmax(q k^T * hd^-0.5) v with the score matrix kept on chip), column sums for bias gradients.
+// Linear layers run on the implicit-GEMM engine of conv.hip (a Linear is a 1x1 convolution over tokens).
+// Activations: tokens [B*T][C] bf16; parameters fp32; statistics / reductions fp32.
+#include "kernels.h"
+
+namespace dali {
+
+__device__ __forceinline__ void unpack8v(const uint4& v, float (&f)[8]) {
+    f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
+    f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
+    f[4] = bf16_bits_to_f32(v.z & 0xffffu); f[5] = bf16_bits_to_f32(v.z >> 16);
+    f[6] = bf16_bits_to_f32(v.w & 0xffffu); f[7] = bf16_bits_to_f32(v.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8v(const float (&f)[8]) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// PatchEmbed_overlap (vit_pytorch.py:251-288): the ps x ps / stride conv as a GEMM over extracted patches.
+// img fp32 [B,3,H,W] -> patches bf16 [B*ny*nx][3*ps*ps], K order (c, r, s) = the conv weight's flattening.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int ps, int stride,
+                                                        int ny, int nx, uint16_t* __restrict__ out) {
+    const int K = 3 * ps * ps, cpr = K >> 3;                       // ps % 8 == 0
+    const size_t total = (size_t)B * ny * nx * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % cpr) * 8;
+        const size_t patch = i / cpr;
+        const int px = (int)(patch % nx), py = (int)((patch / nx) % ny), b = (int)(patch / ((size_t)nx * ny));
+        const int c = k / (ps * ps), rem = k - c * ps * ps, r = rem / ps, s = rem - r * ps;
+        const float* src = img + (((size_t)b * 3 + c) * H + py * stride + r) * W + px * stride + s;
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = src[t];
+        *reinterpret_cast<uint4*>(out + patch * K + k) = pack8v(v);
+    }
+}
+
+// x[b,0,:] = cls + pos[0];  x[b,1+i,:] = pe[b*np+i,:] + pos[1+i]      (vit_pytorch.py:379-391, no SIE)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const uint16_t* __restrict__ pe, const float* __restrict__ cls,
+                                                               const float* __restrict__ pos, int B, int T, int C, uint16_t* __restrict__ x) {
+    const int cpr = C >> 3;
+    const size_t total = (size_t)B * T * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % cpr) * 8;
+        const size_t row = i / cpr;
+        const int t = (int)(row % T), b = (int)(row / T);
+        float v[8];
+        if (t == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = cls[c + q];
+        } else {
+            unpack8v(*reinterpret_cast<const uint4*>(pe + ((size_t)b * (T - 1) + t - 1) * C + c), v);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += pos[(size_t)t * C + c + q];
+        *reinterpret_cast<uint4*>(x + row * C + c) = pack8v(v);
+    }
+}
+// dpos[t,:] = sum_b dx[b,t,:] (fp32; dcls = dpos[0]);  dpe[b*np+i,:] = dx[b,1+i,:]
+__global__ __launch_bounds__(256) void assemble_tokens_bwd_kernel(const uint16_t* __restrict__ dx, int B, int T, int C,
+                                                                   float* __restrict__ dpos, float* __restrict__ dcls, uint16_t* __restrict__ dpe) {
+    const int cpr = C >> 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * cpr) return;
+    const int c = (i % cpr) * 8, t = i / cpr;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(dx + ((size_t)b * T + t) * C + c);
+        float v[8];
+        unpack8v(raw, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += v[q];
+        if (t > 0 && dpe) *reinterpret_cast<uint4*>(dpe + ((size_t)b * (T - 1) + t - 1) * C + c) = raw;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        dpos[(size_t)t * C + c + q] = acc[q];
+        if (t == 0) dcls[c + q] = acc[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (C <= 2048, C % 8 == 0), one wave64 per row.  eps 1e-6 in TransReID (vit_pytorch.py:457).
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXCH = 4;        // 16-byte chunks per lane (C <= 2048)
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int rows, int C, float eps,
+                                                             uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int c = (lane + k * 64) * 8;
+        if (c < C) {
+            unpack8v(*reinterpret_cast<const uint4*>(x + (size_t)row * C + c), v[k]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s += v[k][t];
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int c = (lane + k * 64) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const float d = v[k][t] - mu; q += d * d; }
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int c = (lane + k * 64) * 8;
+        if (c < C) {
+            float o[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = (v[k][t] - mu) * rs * gamma[c + t] + beta[c + t];
+            *reinterpret_cast<uint4*>(y + (size_t)row * C + c) = pack8v(o);
+        }
+    }
+}
+
+// dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat)) (+ add);  per-block partials of
+// dgamma = sum_rows g*xhat and dbeta = sum_rows g   ->  partial[block][C][2]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const uint16_t* __restrict__ add,
+                                                             int rows, int C, int rows_per_block, uint16_t* __restrict__ dx,
+                                                             float* __restrict__ partial) {
+    extern __shared__ float red[];                                  // [4 waves][C][2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[LN_MAXCH][8], db[LN_MAXCH][8];
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { dg[k][t] = 0.f; db[k][t] = 0.f; }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float gv[LN_MAXCH][8], xh[LN_MAXCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            const int c = (lane + k * 64) * 8;
+            if (c < C) {
+                float xv[8];
+                unpack8v(*reinterpret_cast<const uint4*>(g + (size_t)row * C + c), gv[k]);
+                unpack8v(*reinterpret_cast<const uint4*>(x + (size_t)row * C + c), xv);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    xh[k][t] = (xv[t] - mu) * rs;
+                    dg[k][t] += gv[k][t] * xh[k][t];
+                    db[k][t] += gv[k][t];
+                    gv[k][t] *= gamma[c + t];
+                    s1 += gv[k][t];
+                    s2 += gv[k][t] * xh[k][t];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            const int c = (lane + k * 64) * 8;
+            if (c < C) {
+                float o[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o[t] = rs * (gv[k][t] - s1 - xh[k][t] * s2);
+                if (add) {
+                    float a[8];
+                    unpack8v(*reinterpret_cast<const uint4*>(add + (size_t)row * C + c), a);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) o[t] += a[t];
+                }
+                *reinterpret_cast<uint4*>(dx + (size_t)row * C + c) = pack8v(o);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int c = (lane + k * 64) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { red[((size_t)wave * C + c + t) * 2] = dg[k][t]; red[((size_t)wave * C + c + t) * 2 + 1] = db[k][t]; }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * 2; e += 256)
+        partial[(size_t)blockIdx.x * C * 2 + e] = red[e] + red[(size_t)C * 2 + e] + red[(size_t)2 * C * 2 + e] + red[(size_t)3 * C * 2 + e];
+}
+
+// partial[block][C] = sum over the block's rows of y[row][:]  (bias gradients of the linear layers)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __restrict__ y, int rows, int C, int rows_per_block,
+                                                              float* __restrict__ partial) {
+    extern __shared__ float red[];                                  // [rif][C]
+    const int cpr = C >> 3, rif = 256 / min(cpr, 256);
+    const int col = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    // C may exceed 2048 (3072-wide MLP): a thread then owns several chunk columns
+    for (int cc = col; cc < cpr; cc += 256) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (rsub < rif) {
+            for (int row = r0 + rsub; row < r1; row += rif) {
+                float v[8];
+                unpack8v(*reinterpret_cast<const uint4*>(y + (size_t)row * C + cc * 8), v);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] += v[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) red[(size_t)rsub * C + cc * 8 + t] = acc[t];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C; e += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rif; ++r) s += red[(size_t)r * C + e];
+        partial[(size_t)blockIdx.x * C + e] = s;
+    }
+}
+// out[c] = sum_s scratch[s][c*stride + which]  (second level of the fp64 two-level sums)
+__global__ void finish_sum_kernel(const double* __restrict__ scratch, int S, int cols, int stride, int which, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double a = 0.0;
+    for (int s = 0; s < S; ++s) a += scratch[(size_t)s * cols * stride + (size_t)c * stride + which];
+    out[c] = (float)a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-head self-attention, one 256-thread block per (batch, head); T <= 208 tokens, head_dim 64.
+// qkv [B*T][3C] bf16 (q | k | v, head h at columns h*64 of each third, as vit_pytorch.py:155 lays them out).
+// Forward: O = softmax(Q K^T * scale) V, scores never leave the chip.  Per wave: 16 query rows at a time:
+//   S (16 x Tp) by MFMA from LDS-resident Q, K  ->  row softmax in registers  ->  P (bf16) through a per-wave LDS
+//   strip  ->  O = P V with V consumed through ds_read_b64_tr_b16 (key-major storage, k = key).
+// Also writes the row log-sum-exp (lse = max + log(sum)) for the backward.
+// LDS images are plain row-major [Tp][72] bf16 (64 + 8 pad): both the K-contiguous (ds_read_b128) and the transposing
+// (tr_b16) fragment reads work on it.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_TP = 208, ATT_LD = 72, ATT_PK = 224, ATT_HD = 64;
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+
+// A/B fragment with k contiguous in memory: element (row0 + lane&15, k0 + 8*(lane>>4) .. +7)
+__device__ __forceinline__ bf16x8_t frag_k(const uint16_t* base, int ld, int row0, int k0, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(base + (row0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
+}
+// fragment whose k index is the ROW of the LDS image: rows k0 + 8*(lane>>4) .. +7, column n0 + (lane&15)
+__device__ __forceinline__ bf16x8_t frag_tr(const uint16_t* base, int ld, int k0, int n0, int lane) {
+    typedef __attribute__((address_space(3))) s16x4v* lp;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const uint16_t* a0 = base + (k0 + 8 * g + q) * ld + n0 + 4 * p;
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a0);
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a0 + 4 * ld));
+    const s16x8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, size_t row_stride, int T, uint16_t* dst) {
+    // [T][64] bf16 from global (row stride in elements) -> LDS [ATT_TP][ATT_LD], rows >= T zeroed
+    for (int i = threadIdx.x; i < ATT_TP * 8; i += 256) {
+        const int row = i >> 3, ch = i & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < T) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
+        *reinterpret_cast<uint4*>(dst + row * ATT_LD + ch * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
+                                                             uint16_t* __restrict__ out, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    uint16_t* sQ = sm;
+    uint16_t* sK = sQ + ATT_TP * ATT_LD;
+    uint16_t* sV = sK + ATT_TP * ATT_LD;
+    uint16_t* sP = sV + (ATT_PK) * ATT_LD;                         // V padded to 224 rows (zero) for the k loop of P V
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t rs = (size_t)3 * C;
+    const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
+    att_load_tile(base, rs, T, sQ);
+    att_load_tile(base + C, rs, T, sK);
+    att_load_tile(base + 2 * C, rs, T, sV);
+    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += 256) sV[ATT_TP * ATT_LD + i] = 0;
+    __syncthreads();
+    uint16_t* myP = sP + wave * 16 * ATT_PK;
+    for (int i = lane; i < 16 * (ATT_PK - ATT_TP); i += 64) myP[(i / 16) * ATT_PK + ATT_TP + (i & 15)] = 0;   // pad columns stay 0
+    for (int qt = wave; qt < ATT_TP / 16; qt += 4) {
+        if (qt * 16 >= T) break;
+        const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
+        f32x4_t s[ATT_TP / 16];
+#pragma unroll
+        for (int j = 0; j < ATT_TP / 16; ++j) {
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(sK, ATT_LD, j * 16, 0, lane), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(sK, ATT_LD, j * 16, 32, lane), a, 0, 0, 0);
+            s[j] = a;
+        }
+        // row softmax: element (j, r) is row (lane>>4)*4 + r, key j*16 + (lane&15)
+        float m[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+        for (int j = 0; j < ATT_TP / 16; ++j) {
+            const bool valid = j * 16 + (lane & 15) < T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[j][r] = valid ? s[j][r] * scale : -__builtin_inff(); m[r] = fmaxf(m[r], s[j][r]); }
+        }
+        float l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], o, 64));
+            l[r] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < ATT_TP / 16; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[j][r] = expf(s[j][r] - m[r]); l[r] += s[j][r]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) l[r] += __shfl_xor(l[r], o, 64);
+        }
+        // P -> per-wave LDS strip [16][224] bf16
+#pragma unroll
+        for (int j = 0; j < ATT_TP / 16; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                myP[((lane >> 4) * 4 + r) * ATT_PK + j * 16 + (lane & 15)] = f32_to_bf16_bits(s[j][r] / l[r]);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = qt * 16 + (lane >> 4) * 4 + r;
+                if (row < T && lse) lse[(size_t)bh * T + row] = m[r] + logf(l[r]);
+            }
+        }
+        // O = P V : A = P (k = key, contiguous), B[k = key][n = d] = V[key][d] through the transposing read
+        f32x4_t o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < ATT_PK / 32; ++kk) {
+            const bf16x8_t pa = frag_k(myP, ATT_PK, 0, kk * 32, lane);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(sV, ATT_LD, kk * 32, d * 16, lane), o[d], 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = qt * 16 + (lane >> 4) * 4 + r;
+                if (row < T) out[((size_t)b * T + row) * C + h * ATT_HD + d * 16 + (lane & 15)] = f32_to_bf16_bits(o[d][r]);
+            }
+    }
+}
+
+// Backward.  Pass A (a wave owns 16 query rows): recompute P from Q, K and the saved lse; dP = dO V^T;
+// D_i = rowsum(dO * O); dS = P * (dP - D_i) * scale; dQ = dS K (K through the transposing read).  dS and P strips are kept
+// nowhere: pass B (a wave owns 16 keys) recomputes S^T = K Q^T, P^T, dP^T = V dO^T and forms dK = dS^T Q, dV = P^T dO
+// with Q / dO consumed through the transposing read.  No cross-block reduction, no atomics.
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                             const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                             int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    uint16_t* sQ = sm;
+    uint16_t* sK = sQ + ATT_PK * ATT_LD;
+    uint16_t* sV = sK + ATT_PK * ATT_LD;
+    uint16_t* sD = sV + ATT_PK * ATT_LD;                           // dO
+    uint16_t* sP = sD + ATT_PK * ATT_LD;                           // per-wave strips [4][16][224]
+    float* sLse = reinterpret_cast<float*>(sP + 4 * 16 * ATT_PK);  // [224]
+    float* sDi = sLse + ATT_PK;                                    // [224]
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t rs = (size_t)3 * C;
+    const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
+    att_load_tile(base, rs, T, sQ);
+    att_load_tile(base + C, rs, T, sK);
+    att_load_tile(base + 2 * C, rs, T, sV);
+    att_load_tile(d_o + (size_t)b * T * C + h * ATT_HD, C, T, sD);
+    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += 256) {
+        sQ[ATT_TP * ATT_LD + i] = 0; sK[ATT_TP * ATT_LD + i] = 0; sV[ATT_TP * ATT_LD + i] = 0; sD[ATT_TP * ATT_LD + i] = 0;
+    }
+    // D_i = sum_d dO[i][d] * O[i][d]; lse
+    for (int i = threadIdx.x; i < ATT_PK; i += 256) {
+        float acc = 0.f;
+        if (i < T) {
+            const uint16_t* orow = o + ((size_t)b * T + i) * C + h * ATT_HD;
+            const uint16_t* grow = d_o + ((size_t)b * T + i) * C + h * ATT_HD;
+            for (int d = 0; d < ATT_HD; ++d) acc += bf16_bits_to_f32(orow[d]) * bf16_bits_to_f32(grow[d]);
+        }
+        sDi[i] = acc;
+        sLse[i] = (i < T) ? lse[(size_t)bh * T + i] : 0.f;
+    }
+    __syncthreads();
+    uint16_t* myP = sP + wave * 16 * ATT_PK;
+    for (int i = lane; i < 16 * (ATT_PK - ATT_TP); i += 64) myP[(i / 16) * ATT_PK + ATT_TP + (i & 15)] = 0;
+    uint16_t* dq_base = dqkv + (size_t)b * T * rs + h * ATT_HD;
+    // ---- pass A: dQ ----
+    for (int qt = wave; qt < ATT_TP / 16; qt += 4) {
+        if (qt * 16 >= T) break;
+        const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
+        const bf16x8_t ga0 = frag_k(sD, ATT_LD, qt * 16, 0, lane), ga1 = frag_k(sD, ATT_LD, qt * 16, 32, lane);
+        float lrow[4], drow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { lrow[r] = sLse[qt * 16 + (lane >> 4) * 4 + r]; drow[r] = sDi[qt * 16 + (lane >> 4) * 4 + r]; }
+#pragma unroll
+        for (int j = 0; j < ATT_TP / 16; ++j) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(sK, ATT_LD, j * 16, 0, lane), s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(sK, ATT_LD, j * 16, 32, lane), s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, frag_k(sV, ATT_LD, j * 16, 0, lane), dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga1, frag_k(sV, ATT_LD, j * 16, 32, lane), dp, 0, 0, 0);
+            const bool valid = j * 16 + (lane & 15) < T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = valid ? expf(s[r] * scale - lrow[r]) : 0.f;
+                myP[((lane >> 4) * 4 + r) * ATT_PK + j * 16 + (lane & 15)] = f32_to_bf16_bits(p * (dp[r] - drow[r]) * scale);
+            }
+        }
+        f32x4_t dq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < ATT_PK / 32; ++kk) {
+            const bf16x8_t da = frag_k(myP, ATT_PK, 0, kk * 32, lane);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, frag_tr(sK, ATT_LD, kk * 32, d * 16, lane), dq[d], 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = qt * 16 + (lane >> 4) * 4 + r;
+                if (row < T) dq_base[(size_t)row * rs + d * 16 + (lane & 15)] = f32_to_bf16_bits(dq[d][r]);
+            }
+    }
+    // ---- pass B: dK, dV (rows = keys, columns = queries) ----
+    for (int kt = wave; kt < ATT_TP / 16; kt += 4) {
+        if (kt * 16 >= T) break;
+        const bf16x8_t ka0 = frag_k(sK, ATT_LD, kt * 16, 0, lane), ka1 = frag_k(sK, ATT_LD, kt * 16, 32, lane);
+        const bf16x8_t va0 = frag_k(sV, ATT_LD, kt * 16, 0, lane), va1 = frag_k(sV, ATT_LD, kt * 16, 32, lane);
+        f32x4_t dk[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4_t dv[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // P^T strip first (for dV), then overwritten by dS^T (for dK): two sweeps over the queries
+        for (int sweep = 0; sweep < 2; ++sweep) {
+#pragma unroll
+            for (int j = 0; j < ATT_TP / 16; ++j) {                 // query tile j
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, frag_k(sQ, ATT_LD, j * 16, 0, lane), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, frag_k(sQ, ATT_LD, j * 16, 32, lane), st, 0, 0, 0);
+                if (sweep == 1) {
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, frag_k(sD, ATT_LD, j * 16, 0, lane), dpt, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, frag_k(sD, ATT_LD, j * 16, 32, lane), dpt, 0, 0, 0);
+                }
+                const int qi = j * 16 + (lane & 15);               // query index = column
+                const float lq = sLse[qi], dq_i = sDi[qi];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + (lane >> 4) * 4 + r;
+                    const float p = (qi < T && key < T) ? expf(st[r] * scale - lq) : 0.f;
+                    const float val = sweep == 0 ? p : p * (dpt[r] - dq_i) * scale;
+                    myP[((lane >> 4) * 4 + r) * ATT_PK + qi] = f32_to_bf16_bits(val);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < ATT_PK / 32; ++kk) {
+                const bf16x8_t a = frag_k(myP, ATT_PK, 0, kk * 32, lane);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (sweep == 0) dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sD, ATT_LD, kk * 32, d * 16, lane), dv[d], 0, 0, 0);
+                    else dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sQ, ATT_LD, kk * 32, d * 16, lane), dk[d], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + (lane >> 4) * 4 + r;
+                if (key < T) {
+                    dq_base[(size_t)key * rs + C + d * 16 + (lane & 15)] = f32_to_bf16_bits(dk[d][r]);
+                    dq_base[(size_t)key * rs + 2 * C + d * 16 + (lane & 15)] = f32_to_bf16_bits(dv[d][r]);
+                }
+            }
+    }
+}
+
+static inline int vgrid(size_t items, int cap = 16384) {
+    size_t b = (items + 255) / 256;
+    if (b > (size_t)cap) b = cap;
+    return b < 1 ? 1 : (int)b;
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------
+int launch_patchify(hipStream_t st, const float* img, int B, int H, int W, int ps, int stride, uint16_t* out) {
+    const int ny = (H - ps) / stride + 1, nx = (W - ps) / stride + 1;
+    hipLaunchKernelGGL(patchify_kernel, dim3(vgrid((size_t)B * ny * nx * (3 * ps * ps / 8))), dim3(256), 0, st, img, B, H, W, ps, stride, ny, nx, out);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_assemble_tokens(hipStream_t st, const uint16_t* pe, const float* cls, const float* pos, int B, int T, int C, uint16_t* x) {
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(vgrid((size_t)B * T * (C / 8))), dim3(256), 0, st, pe, cls, pos, B, T, C, x);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_assemble_tokens_bwd(hipStream_t st, const uint16_t* dx, int B, int T, int C, float* dpos, float* dcls, uint16_t* dpe) {
+    hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3((T * (C / 8) + 255) / 256), dim3(256), 0, st, dx, B, T, C, dpos, dcls, dpe);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_layernorm_fwd(hipStream_t st, const uint16_t* x, const float* gamma, const float* beta, int rows, int C, float eps,
+                         uint16_t* y, float* mean, float* rstd) {
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, rows, C, eps, y, mean, rstd);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+static int rows_blocks(int rows, int per_iter, int* rpb) {
+    int blocks = (rows + per_iter * 8 - 1) / (per_iter * 8);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    int r = (rows + blocks - 1) / blocks;
+    r = (r + per_iter - 1) / per_iter * per_iter;
+    *rpb = r;
+    return (rows + r - 1) / r;
+}
+size_t layernorm_bwd_partial_floats(int rows, int C) { int rpb; return (size_t)rows_blocks(rows, 4, &rpb) * C * 2; }
+int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean, const float* rstd,
+                         const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta, float* partial, double* scratch) {
+    int rpb;
+    const int blocks = rows_blocks(rows, 4, &rpb);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), (size_t)4 * C * 2 * sizeof(float), st, g, x, gamma, mean, rstd, add, rows, C,
+                       rpb, dx, partial);
+    DALI_LAUNCH_CHECK();
+    int S, rc;
+    if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
+    hipLaunchKernelGGL(finish_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 0, dgamma);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 1, dbeta);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+size_t colsum_partial_floats(int rows, int C) { int rpb; const int rif = 256 / ((C / 8) < 256 ? (C / 8) : 256); return (size_t)rows_blocks(rows, rif, &rpb) * C; }
+int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out, float* partial, double* scratch) {
+    const int cpr = C / 8, rif = 256 / (cpr < 256 ? cpr : 256);
+    int rpb;
+    const int blocks = rows_blocks(rows, rif, &rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), (size_t)rif * C * sizeof(float), st, y, rows, C, rpb, partial);
+    DALI_LAUNCH_CHECK();
+    int S, rc;
+    if ((rc = reduce_partials(st, partial, blocks, C, scratch, &S))) return rc;
+    hipLaunchKernelGGL(finish_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 1, 0, out);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+constexpr size_t ATT_FWD_LDS = ((size_t)2 * ATT_TP * ATT_LD + (size_t)ATT_PK * ATT_LD + 4 * 16 * ATT_PK) * 2;
+constexpr size_t ATT_BWD_LDS = ((size_t)4 * ATT_PK * ATT_LD + 4 * 16 * ATT_PK) * 2 + 2 * ATT_PK * 4;
+int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
+    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_FWD_LDS));
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), ATT_FWD_LDS, st, qkv, B, T, H, scale, out, lse);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
+                         float scale, uint16_t* dqkv) {
+    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_BWD_LDS));
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), ATT_BWD_LDS, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+}  // namespace dali
+
+// ---- single-op C ABI ----------------------------------------------------------------------------------
+using namespace dali;
+
+extern "C" int dali_vit_patchify(dali_ctx* ctx, void* stream, const float* img, int B, int H, int W, int patch, int stride, uint16_t* out) {
+    DALI_REQUIRE(ctx && img && out, "dali_vit_patchify: null argument");
+    DALI_REQUIRE(patch % 8 == 0 && stride > 0 && H >= patch && W >= patch, "dali_vit_patchify: bad geometry");
+    return launch_patchify((hipStream_t)stream, img, B, H, W, patch, stride, out);
+}
+extern "C" int dali_vit_assemble_tokens(dali_ctx* ctx, void* stream, const uint16_t* patch_emb, const float* cls, const float* pos, int B, int T,
+                                        int C, uint16_t* x) {
+    DALI_REQUIRE(ctx && patch_emb && cls && pos && x && C % 8 == 0, "dali_vit_assemble_tokens: bad argument");
+    return launch_assemble_tokens((hipStream_t)stream, patch_emb, cls, pos, B, T, C, x);
+}
+extern "C" int dali_vit_assemble_tokens_bwd(dali_ctx* ctx, void* stream, const uint16_t* dx, int B, int T, int C, float* dpos, float* dcls,
+                                            uint16_t* dpatch_emb) {
+    DALI_REQUIRE(ctx && dx && dpos && dcls && C % 8 == 0, "dali_vit_assemble_tokens_bwd: bad argument");
+    return launch_assemble_tokens_bwd((hipStream_t)stream, dx, B, T, C, dpos, dcls, dpatch_emb);
+}
+extern "C" int dali_layernorm_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const float* gamma, const float* beta, int rows, int C,
+                                  float eps, uint16_t* y, float* mean, float* rstd) {
+    DALI_REQUIRE(ctx && x && gamma && beta && y && mean && rstd, "dali_layernorm_fwd: null argument");
+    DALI_REQUIRE(C % 8 == 0 && C <= 2048 && rows > 0, "dali_layernorm_fwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
+    return launch_layernorm_fwd((hipStream_t)stream, x, gamma, beta, rows, C, eps, y, mean, rstd);
+}
+extern "C" int dali_layernorm_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean,
+                                  const float* rstd, const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta) {
+    DALI_REQUIRE(ctx && g && x && gamma && mean && rstd && dx && dgamma && dbeta, "dali_layernorm_bwd: null argument");
+    DALI_REQUIRE(C % 8 == 0 && C <= 2048 && rows > 0, "dali_layernorm_bwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
+    const size_t part = align_up(layernorm_bwd_partial_floats(rows, C) * 4, 256);
+    char* ws = static_cast<char*>(workspace(ctx, part + reduce_scratch_bytes(C, 2)));
+    if (!ws) return DALI_ERR_NOMEM;
+    return launch_layernorm_bwd((hipStream_t)stream, g, x, gamma, mean, rstd, add, rows, C, dx, dgamma, dbeta, reinterpret_cast<float*>(ws),
+                                reinterpret_cast<double*>(ws + part));
+}
+extern "C" int dali_attention_fwd(dali_ctx* ctx, void* stream, const uint16_t* qkv, int B, int T, int H, int head_dim, float scale,
+                                  uint16_t* out, float* lse) {
+    DALI_REQUIRE(ctx && qkv && out, "dali_attention_fwd: null argument");
+    DALI_REQUIRE(head_dim == ATT_HD && T > 0 && T <= ATT_TP, "dali_attention_fwd: head_dim must be %d and T <= %d (got %d, %d)", ATT_HD, ATT_TP, head_dim, T);
+    return launch_attention_fwd((hipStream_t)stream, qkv, B, T, H, scale, out, lse);
+}
+extern "C" int dali_attention_bwd(dali_ctx* ctx, void* stream, const uint16_t* qkv, const uint16_t* out, const uint16_t* d_out, const float* lse,
+                                  int B, int T, int H, int head_dim, float scale, uint16_t* dqkv) {
+    DALI_REQUIRE(ctx && qkv && out && d_out && lse && dqkv, "dali_attention_bwd: null argument");
+    DALI_REQUIRE(head_dim == ATT_HD && T > 0 && T <= ATT_TP, "dali_attention_bwd: head_dim must be %d and T <= %d", ATT_HD, ATT_TP);
+    return launch_attention_bwd((hipStream_t)stream, qkv, out, d_out, lse, B, T, H, scale, dqkv);
+}

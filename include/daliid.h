@@ -151,6 +151,38 @@ int dali_bn1d_fwd(dali_ctx* ctx, void* stream, const float* x, int n, int C, con
 int dali_bn1d_bwd(dali_ctx* ctx, void* stream, const float* x, const float* dy, int n, int C, const float* gamma,
                   const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta);
 
+/* ---- TransReID ViT encoder pieces (vit_pytorch.py:120-184, 251-288, 375-408; make_models.py:184-205) -------- *
+ * Tokens are [rows = B*T][C] bf16.  Linear layers (nn.Linear / the patch-embedding conv) run on the implicit-GEMM
+ * engine: weights bf16 [N][K] (torch layout), the dgrad image is the transpose [K][N]. */
+/* y = act(x @ w^T + bias) (+ residual); act 0 none / 1 exact-erf GELU (Mlp, vit_pytorch.py:120-136); pre (nullable)
+ * receives the pre-activation.  K % 32 == 0, N % 4 == 0. */
+int dali_linear_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, const float* bias, int act,
+                    const uint16_t* residual, uint16_t* y, uint16_t* pre, int rows, int K, int N);
+/* dx = (dy @ wt^T) * gelu'(gelu_pre) (+ residual). */
+int dali_linear_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, const uint16_t* gelu_pre,
+                      const uint16_t* residual, uint16_t* dx, int rows, int K, int N);
+/* dw[N][K] fp32 = dy^T @ x; dbias[N] fp32 (nullable) = column sums of dy. */
+int dali_linear_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, int rows,
+                      int K, int N);
+/* PatchEmbed_overlap (vit_pytorch.py:251-288): images fp32 NCHW -> patches bf16 [B*ny*nx][3*patch*patch] in (c,r,s) order. */
+int dali_vit_patchify(dali_ctx* ctx, void* stream, const float* img, int B, int H, int W, int patch, int stride, uint16_t* out);
+/* x[b,0] = cls + pos[0]; x[b,1+i] = patch_emb[b,i] + pos[1+i] (vit_pytorch.py:379-391, camera = view = 0), and backward. */
+int dali_vit_assemble_tokens(dali_ctx* ctx, void* stream, const uint16_t* patch_emb, const float* cls, const float* pos, int B, int T,
+                             int C, uint16_t* x);
+int dali_vit_assemble_tokens_bwd(dali_ctx* ctx, void* stream, const uint16_t* dx, int B, int T, int C, float* dpos, float* dcls,
+                                 uint16_t* dpatch_emb);
+/* nn.LayerNorm over C (eps 1e-6 in TransReID); backward optionally adds the residual-stream gradient `add`. */
+int dali_layernorm_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const float* gamma, const float* beta, int rows, int C,
+                       float eps, uint16_t* y, float* mean, float* rstd);
+int dali_layernorm_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean,
+                       const float* rstd, const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta);
+/* Attention (vit_pytorch.py:152-164): qkv [B*T][3*H*64] -> out [B*T][H*64] = softmax(q k^T * scale) v per head, scores on chip;
+ * lse [B*H][T] (row log-sum-exp) feeds the backward, which recomputes the probabilities.  T <= 208, head_dim 64. */
+int dali_attention_fwd(dali_ctx* ctx, void* stream, const uint16_t* qkv, int B, int T, int H, int head_dim, float scale,
+                       uint16_t* out, float* lse);
+int dali_attention_bwd(dali_ctx* ctx, void* stream, const uint16_t* qkv, const uint16_t* out, const uint16_t* d_out, const float* lse,
+                       int B, int T, int H, int head_dim, float scale, uint16_t* dqkv);
+
 /* ---- loss heads (train_encodersKIT.py:200-208), fp32 --------------------------------------------------- *
  * S is the similarity matrix fn @ C^T (dali_pairdist with DALI_METRIC_DOT).  labels are int32 codes shared between
  * the batch and the center / proxy label arrays; w[i] is the distortion weight table[samples_distortion[i]]
