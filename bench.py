@@ -209,10 +209,46 @@ def make_train_state(args, world, rank, batch, device):
     return tr, heads, imgs, labels, w, acc
 
 
+VIT_B16_GFLOP_PER_IMAGE = 105.378      # fwd+bwd GEMM FLOPs per 224x224 image
+
+
+def make_vit_state(args, world, rank, batch, device):
+    """configs[3]: TransReID ViT-B/16 (vit_pytorch.py) + BN neck, 224x224, bf16, same heads / Adam / EMA as configs[1]
+    (the reference has no training route for it; the build wires it into the same trainer)."""
+    from daliid_amd import vit_pytorch as V
+    from daliid_amd.losses import LossHeads, _sample_weights
+    from daliid_amd.train_encodersKIT import trainer
+    from daliid_amd.ops_eval import l2norm_rows
+    gen = torch.Generator(device=device).manual_seed(12 + rank)
+    mk = lambda: V.ViTNeckNet(img_size=(224, 224), patch_size=16, stride_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                              drop_path_rate=0.0, device=device, seed=12)
+    online, momentum = mk(), mk()
+    NC, D = 1024, 768
+    centers = l2norm_rows(torch.randn(NC, D, device=device, generator=torch.Generator(device=device).manual_seed(1)))
+    proxies = l2norm_rows(torch.randn(5 * NC, D, device=device, generator=torch.Generator(device=device).manual_seed(2)))
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        pg = dist.group.WORLD
+    drv = torch.optim.Adam([p for p in online.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    tr = trainer("Synthetic", None, "vit_base", {}, 224, 224, None, False, 1, drv, batch // 16, 16, 0.05, 0.999, 0.4, 250, online, momentum,
+                 [device.index], "bench", process_group=pg)
+    heads = LossHeads(centers, torch.arange(NC).numpy(), proxies, torch.arange(NC).repeat_interleave(5).numpy(), 0.05, 0.4, pg)
+    imgs = torch.randn(batch, 3, 224, 224, device=device, generator=gen)
+    P = batch // 16
+    labels = ((torch.arange(P, device=device) + rank * P) % NC).repeat_interleave(16).to(torch.int32)
+    distortion = torch.stack((torch.zeros(batch // 2, dtype=torch.long), torch.randint(1, 6, (batch // 2,))), 1).reshape(-1)
+    w = _sample_weights(distortion, 10, 250, device)
+    online.train(); momentum.eval()
+    return tr, heads, imgs, labels, w, torch.zeros(6, device=device)
+
+
 def bench_train(args, world, rank):
     device = torch.device("cuda", torch.cuda.current_device())
-    batch = args.batch
-    tr, heads, imgs, labels, w, acc = make_train_state(args, world, rank, batch, device)
+    vit = args.workload == "vit"
+    batch = args.batch if args.batch else (128 if vit else 256)
+    gflop_img = VIT_B16_GFLOP_PER_IMAGE if vit else RESNET50_GFLOP_PER_IMAGE
+    tr, heads, imgs, labels, w, acc = (make_vit_state if vit else make_train_state)(args, world, rank, batch, device)
     step = lambda: tr.train_step(heads, imgs, labels, w, acc)
     log("train state built (batch %d per GPU); warmup x%d" % (batch, args.warmup))
     for _ in range(args.warmup):
@@ -230,19 +266,21 @@ def bench_train(args, world, rank):
     gpu_ms = ev0.elapsed_time(ev1) / args.steps
     ms_step = dt / args.steps * 1e3
     ips = world * batch / (dt / args.steps)
-    tflops = batch * RESNET50_GFLOP_PER_IMAGE / 1e3 / (gpu_ms * 1e-3)
-    roofline = {"kernel": "train step (all conv MFMA kernels: igemm_conv_kernel / igemm_wgrad_kernel)", "bound": "mfma",
+    tflops = batch * gflop_img / 1e3 / (gpu_ms * 1e-3)
+    roofline = {"kernel": "train step (all MFMA GEMM kernels: igemm_conv_dma_kernel / igemm_wgrad_dma_kernel%s)" % (" / attention" if vit else ""),
+                "bound": "mfma",
                 "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                "note": "algorithmic conv FLOPs (24.32 GFLOP/img) / device time of the whole step between HIP events on the launch stream"}
+                "note": "algorithmic GEMM FLOPs (%.2f GFLOP/img) / device time of the whole step between HIP events on the launch stream" % gflop_img}
     final = acc.cpu().numpy()
     log("GPU: %.3f ms/step (device %.3f ms), %.1f images/s" % (ms_step, gpu_ms, ips))
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not vit:
         cpu = cpu_baseline_train()
+    wl = ("configs[3]: TransReID ViT-B/16 bf16 224x224, batch %d per GPU, center+proxy heads, Adam, EMA" % batch) if vit else \
+         "configs[1]: ResNet-50 ReID bf16 256x128, PK batch 16x16=256 per GPU, center+proxy heads, Adam, EMA"
     return {"metric": "images/sec (train step)", "value": round(ips, 2), "unit": "images/s", "ms_per_step": round(ms_step, 3),
-            "dtype": "bf16", "config": {"workload": "configs[1]: ResNet-50 ReID bf16 256x128, PK batch 16x16=256 per GPU, center+proxy heads, "
-                                                    "Adam, EMA%s" % ("; data-parallel, RCCL all-reduce of gradients" if world > 1 else ""),
+            "dtype": "bf16", "config": {"workload": wl + ("; data-parallel, RCCL all-reduce of gradients" if world > 1 else ""),
                                         "global_batch": world * batch, "per_gpu_batch": batch, "parallelism": "dp%d" % world,
                                         "mean_loss": float(final[2] / max(final[4], 1))},
             "roofline": roofline, "cpu_baseline": cpu}
@@ -285,13 +323,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=["train", "distance"])
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch of the train workload")
+    ap.add_argument("--workload", default="train", choices=["train", "vit", "distance"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 256 for train, 128 for vit)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     world, rank, local = dist_setup(args.gpus)
-    res = bench_train(args, world, rank) if args.workload == "train" else bench_distance(args, world, rank)
+    res = bench_distance(args, world, rank) if args.workload == "distance" else bench_train(args, world, rank)
     res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
     if rank == 0:

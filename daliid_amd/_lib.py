@@ -76,6 +76,14 @@ _SIGNATURES = {
     "dali_resnet_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "dali_resnet_backward": [c_void_p, c_void_p, c_void_p, c_int, c_int],
     "dali_resnet_debug_tensor": [c_void_p, ctypes.c_char_p, c_void_p, c_void_p],
+    "dali_vit_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],
+    "dali_vit_destroy": [c_void_p],
+    "dali_vit_sizes": [c_void_p] + [c_void_p] * 6,
+    "dali_vit_tensor_info": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "dali_vit_bind": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t],
+    "dali_vit_refresh_weights": [c_void_p, c_void_p],
+    "dali_vit_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "dali_vit_backward": [c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"dali_last_error": ctypes.c_char_p}
 

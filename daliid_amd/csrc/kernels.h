@@ -95,10 +95,11 @@ int launch_patchify(hipStream_t st, const float* img, int B, int H, int W, int p
 int launch_assemble_tokens(hipStream_t st, const uint16_t* pe, const float* cls, const float* pos, int B, int T, int C, uint16_t* x);
 int launch_assemble_tokens_bwd(hipStream_t st, const uint16_t* dx, int B, int T, int C, float* dpos, float* dcls, uint16_t* dpe);
 int launch_layernorm_fwd(hipStream_t st, const uint16_t* x, const float* gamma, const float* beta, int rows, int C, float eps,
-                         uint16_t* y, float* mean, float* rstd);
+                         uint16_t* y, float* mean, float* rstd, float* y32);
 size_t layernorm_bwd_partial_floats(int rows, int C);
 int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean, const float* rstd,
-                         const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta, float* partial, double* scratch);
+                         const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta, float* partial, double* scratch,
+                         const float* g32 = nullptr);
 size_t colsum_partial_floats(int rows, int C);
 int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out, float* partial, double* scratch);
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse);

@@ -89,7 +89,8 @@ constexpr int LN_MAXCH = 4;        // 16-byte chunks per lane (C <= 2048)
 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int rows, int C, float eps,
-                                                             uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                             uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ y32) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -123,7 +124,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const uint16_t* __re
             float o[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) o[t] = (v[k][t] - mu) * rs * gamma[c + t] + beta[c + t];
-            *reinterpret_cast<uint4*>(y + (size_t)row * C + c) = pack8v(o);
+            if (y) *reinterpret_cast<uint4*>(y + (size_t)row * C + c) = pack8v(o);
+            if (y32) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) y32[(size_t)row * C + c + t] = o[t];
+            }
         }
     }
 }
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const uint16_t* __restrict__ add,
                                                              int rows, int C, int rows_per_block, uint16_t* __restrict__ dx,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, const float* __restrict__ g32) {
     extern __shared__ float red[];                                  // [4 waves][C][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[LN_MAXCH][8], db[LN_MAXCH][8];
@@ -152,7 +157,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
             const int c = (lane + k * 64) * 8;
             if (c < C) {
                 float xv[8];
-                unpack8v(*reinterpret_cast<const uint4*>(g + (size_t)row * C + c), gv[k]);
+                if (g32) {                                          // fp32 upstream gradient (final LayerNorm under the BN neck)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) gv[k][t] = g32[(size_t)row * C + c + t];
+                } else {
+                    unpack8v(*reinterpret_cast<const uint4*>(g + (size_t)row * C + c), gv[k]);
+                }
                 unpack8v(*reinterpret_cast<const uint4*>(x + (size_t)row * C + c), xv);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
@@ -510,8 +520,8 @@ int launch_assemble_tokens_bwd(hipStream_t st, const uint16_t* dx, int B, int T,
     return DALI_OK;
 }
 int launch_layernorm_fwd(hipStream_t st, const uint16_t* x, const float* gamma, const float* beta, int rows, int C, float eps,
-                         uint16_t* y, float* mean, float* rstd) {
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, rows, C, eps, y, mean, rstd);
+                         uint16_t* y, float* mean, float* rstd, float* y32) {
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, rows, C, eps, y, mean, rstd, y32);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -526,11 +536,12 @@ static int rows_blocks(int rows, int per_iter, int* rpb) {
 }
 size_t layernorm_bwd_partial_floats(int rows, int C) { int rpb; return (size_t)rows_blocks(rows, 4, &rpb) * C * 2; }
 int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean, const float* rstd,
-                         const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta, float* partial, double* scratch) {
+                         const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta, float* partial, double* scratch,
+                         const float* g32) {
     int rpb;
     const int blocks = rows_blocks(rows, 4, &rpb);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), (size_t)4 * C * 2 * sizeof(float), st, g, x, gamma, mean, rstd, add, rows, C,
-                       rpb, dx, partial);
+                       rpb, dx, partial, g32);
     DALI_LAUNCH_CHECK();
     int S, rc;
     if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
@@ -593,7 +604,7 @@ extern "C" int dali_layernorm_fwd(dali_ctx* ctx, void* stream, const uint16_t* x
                                   float eps, uint16_t* y, float* mean, float* rstd) {
     DALI_REQUIRE(ctx && x && gamma && beta && y && mean && rstd, "dali_layernorm_fwd: null argument");
     DALI_REQUIRE(C % 8 == 0 && C <= 2048 && rows > 0, "dali_layernorm_fwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
-    return launch_layernorm_fwd((hipStream_t)stream, x, gamma, beta, rows, C, eps, y, mean, rstd);
+    return launch_layernorm_fwd((hipStream_t)stream, x, gamma, beta, rows, C, eps, y, mean, rstd, nullptr);
 }
 extern "C" int dali_layernorm_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean,
                                   const float* rstd, const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta) {
@@ -603,7 +614,7 @@ extern "C" int dali_layernorm_bwd(dali_ctx* ctx, void* stream, const uint16_t* g
     char* ws = static_cast<char*>(workspace(ctx, part + reduce_scratch_bytes(C, 2)));
     if (!ws) return DALI_ERR_NOMEM;
     return launch_layernorm_bwd((hipStream_t)stream, g, x, gamma, mean, rstd, add, rows, C, dx, dgamma, dbeta, reinterpret_cast<float*>(ws),
-                                reinterpret_cast<double*>(ws + part));
+                                reinterpret_cast<double*>(ws + part), nullptr);
 }
 extern "C" int dali_attention_fwd(dali_ctx* ctx, void* stream, const uint16_t* qkv, int B, int T, int H, int head_dim, float scale,
                                   uint16_t* out, float* lse) {

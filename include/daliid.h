@@ -251,6 +251,29 @@ int dali_resnet_forward(dali_resnet* net, void* stream, const float* images, int
 int dali_resnet_backward(dali_resnet* net, void* stream, const float* d_emb, int stage_begin, int stage_end);
 int dali_resnet_debug_tensor(dali_resnet* net, const char* name, void** ptr, int64_t* bytes);
 
+/* ---- net plan: TransReID ViT + BN neck (make_models.build_transformer.forward, make_models.py:184-205) ----- *
+ * Same storage contract as dali_resnet_*.  forward: images fp32 NCHW -> feat fp32 [batch, dim] (after the
+ * BatchNorm1d neck); global_feat (nullable) receives the pre-neck cls feature.  DropPath / Dropout are identity
+ * (rate 0).  Limits: head_dim 64, at most 208 tokens. */
+typedef struct dali_vit dali_vit;
+typedef struct {
+    int batch, height, width;   /* images fp32 NCHW [batch,3,height,width] */
+    int patch, stride;          /* 16, 16 for ViT-B/16; stride < patch = overlapping patches (PatchEmbed_overlap) */
+    int dim, depth, heads;      /* 768, 12, 12 */
+    int mlp_hidden;             /* 3072 */
+    int num_classes;            /* size of the unused `base.fc` head kept for state_dict compatibility (1000) */
+} dali_vit_cfg;
+int dali_vit_create(dali_ctx* ctx, const dali_vit_cfg* cfg, dali_vit** out);
+int dali_vit_destroy(dali_vit* net);
+int dali_vit_sizes(const dali_vit* net, int64_t* param_elems, int64_t* buffer_elems, int64_t* arena_bytes, int* feat_dim,
+                   int* n_params, int* n_buffers);
+int dali_vit_tensor_info(const dali_vit* net, int kind, int index, char* name, int name_cap, int64_t* offset, int64_t* numel,
+                         int* shape4, int* ndim);
+int dali_vit_bind(dali_vit* net, float* params, float* grads, float* buffers, void* arena, size_t arena_bytes);
+int dali_vit_refresh_weights(dali_vit* net, void* stream);
+int dali_vit_forward(dali_vit* net, void* stream, const float* images, int training, float* feat, float* global_feat);
+int dali_vit_backward(dali_vit* net, void* stream, const float* d_feat);
+
 #ifdef __cplusplus
 }
 #endif
