@@ -14,6 +14,7 @@
 // (c) the dgrad epilogue can add a residual gradient.
 #include "gemm_tile.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace dali {
 
@@ -241,7 +242,20 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 constexpr uint32_t DMA_OOB = 0x7ffffff0u;
 
-template <int TM, int TN>
+// wait until at most N of this wave's vector-memory operations (the LDS-DMA loads) are still in flight; also drains
+// this wave's LDS reads so the following barrier orders them against the next refill
+template <int N>
+__device__ __forceinline__ void dma_wait() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else static_assert(N == 0, "unsupported DMA count");
+}
+
+template <int TM, int TN, int NSTAGE>
 __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
     constexpr int FM = Cfg::FM, FN = Cfg::FN;
@@ -325,12 +339,20 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     const int frag_off = (lane & 15) * 32 + (((lane >> 4) ^ lds_swz(lane & 15)) << 3);
     const int a_row0 = wm * (TM / 2), b_row0 = wn * (TN / 2);
 
+    // 3-stage ring: the DMA of tile t+2 is issued before tile t is multiplied; the wait at the end of iteration t retires
+    // tile t+1 only (counted vmcnt leaves tile t+2's A_BLK+B_BLK DMAs in flight ACROSS the barrier, so a raw s_barrier is
+    // used: __syncthreads() would drain them).  A stage is read one iteration after the wait+barrier that retired it, and
+    // re-filled two barriers after its last read.
+    constexpr int NDMA = A_BLK + B_BLK;
+    constexpr int AHEAD = NSTAGE - 1;                   // tiles in flight beyond the one being multiplied
     issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (AHEAD == 2 && ktiles > 1) issue(1);
+    if (AHEAD == 2 && ktiles > 1) dma_wait<NDMA>(); else dma_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    int st_cur = 0, st_nxt2 = AHEAD;
     for (int kt = 0; kt < ktiles; ++kt) {
-        if (kt + 1 < ktiles) issue((kt + 1) & 1);
-        const uint16_t* sa = smem + (kt & 1) * Cfg::STAGE_ELEMS;
+        if (kt + AHEAD < ktiles) issue(st_nxt2);
+        const uint16_t* sa = smem + st_cur * Cfg::STAGE_ELEMS;
         const uint16_t* sb = sa + Cfg::A_ELEMS;
         bf16x8_t fa[FM];
 #pragma unroll
@@ -341,9 +363,12 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
 #pragma unroll
             for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (AHEAD == 2 && kt + 2 < ktiles) dma_wait<NDMA>(); else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
+        st_nxt2 = (st_nxt2 == NSTAGE - 1) ? 0 : st_nxt2 + 1;
     }
+    __syncthreads();
 
     conv_epilogue<Cfg>(a, acc, tm, tn, smem);
 }
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WGradArgs a, int tiles
 // streamed by `buffer_load_dwordx4 ... lds` (1 KiB block = 4 pixel rows x 256 B), swizzle applied on the source chunk.
 __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int tiles_m, int tiles_n) {
     constexpr int TILE = 32 * 128;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 2 * TILE];
+    __shared__ __attribute__((aligned(16))) uint16_t smem[3 * 2 * TILE];          // 3-stage ring, 48 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -539,13 +564,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (ksteps > 0) {
+    if (ksteps > 0) {                                   // same 3-stage ring / counted-vmcnt schedule as igemm_conv_dma_kernel
         issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (ksteps > 1) issue(1, 1);
+        if (ksteps > 1) dma_wait<4>(); else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        int st_cur = 0, st_nxt2 = 2;
         for (int kt = 0; kt < ksteps; ++kt) {
-            if (kt + 1 < ksteps) issue(kt + 1, (kt + 1) & 1);
-            const uint16_t* sa = smem + (kt & 1) * 2 * TILE;
+            if (kt + 2 < ksteps) issue(kt + 2, st_nxt2);
+            const uint16_t* sa = smem + st_cur * 2 * TILE;
             const uint16_t* sb = sa + TILE;
             bf16x8_t fa[4];
 #pragma unroll
@@ -556,8 +583,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (kt + 2 < ksteps) dma_wait<4>(); else dma_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            st_cur = (st_cur == 2) ? 0 : st_cur + 1;
+            st_nxt2 = (st_nxt2 == 2) ? 0 : st_nxt2 + 1;
         }
     }
     float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
@@ -633,25 +662,37 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     // the LDS-DMA kernel addresses both tensors with 32-bit byte offsets through buffer descriptors
     const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
     const bool dma_ok = !in_bn && x_bytes < 0x7ff00000ll && (long long)a.Cm * a.g.R * a.g.S * a.g.Ck * 2 < 0x7ff00000ll;
+    static int cfg_override = -2;
+    if (cfg_override == -2) { const char* e = getenv("DALI_CONV_CFG"); cfg_override = e ? atoi(e) : -1; }
     if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<64, 256, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
-        else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<64, 256, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+    } else if (dma_ok && ((cfg_override == 2 || cfg_override == 3) && a.Cm >= 256)) {
+        using Cfg = GemmCfg<256, 128, 1, 1, 1>;
+        const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 127) / 128;
+        const int grid = xcd_tile_grid(tiles_m, tiles_n);
+        if (cfg_override == 2) hipLaunchKernelGGL((igemm_conv_dma_kernel<256, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_dma_kernel<256, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES / 2 * 3));
+            hipLaunchKernelGGL((igemm_conv_dma_kernel<256, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
+        }
     } else {
         using Cfg = GemmCfg<128, 128, 1, 1, 1>;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<128, 128, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
-        else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok && cfg_override == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
     }
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-int igemm_conv_stat_tiles(int Cm, int P) { return Cm <= 64 ? (P + 255) / 256 : (P + 127) / 128; }
+int igemm_conv_stat_tiles(int Cm, int P) { return Cm <= 64 ? (P + 255) / 256 : (P + 127) / 128; }   // every wide config uses TN = 128
 
 // Chooses the split count so that the grid has ~target blocks; returns slab bytes through *ws_bytes.
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes) {

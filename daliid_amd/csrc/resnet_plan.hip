@@ -443,16 +443,17 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     if ((rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
     uint16_t* d_a2 = next_gbuf(net, dz, d_raw3, d_rawd);
     if ((rc = conv_dgrad(net, st, b.c3, d_raw3, nullptr, d_a2))) return rc;
-    // bn2 + relu (mask = a2 > 0), in place
+    // bn2 + relu, in place.  The ReLU mask is recomputed from raw2 (raw*scale+shift > 0 <=> a2 > 0: bf16 rounding cannot
+    // flush a positive fp32 to zero) instead of reading a2: one tensor read less in each of the two passes.
     BnBwdSide s2{b.raw2, b.b2.mean, b.b2.invstd, b.b2.scale, b.b2.shift};
-    if ((rc = launch_bn_bwd(st, d_a2, b.a2, s2, nullptr, 1, Pout, b.width, net->bwd_partial, b.b2.coef, nullptr, net->G + b.b2.g_off,
+    if ((rc = launch_bn_bwd(st, d_a2, nullptr, s2, nullptr, 1, Pout, b.width, net->bwd_partial, b.b2.coef, nullptr, net->G + b.b2.g_off,
                             net->G + b.b2.b_off, nullptr, nullptr, d_a2, nullptr, nullptr, net->red_scratch))) return rc;
     // conv2
     if ((rc = conv_wgrad(net, st, b.c2, b.a1, nullptr, d_a2))) return rc;
     uint16_t* d_a1 = d_raw3;                                      // d_raw3 is dead now
     if ((rc = conv_dgrad(net, st, b.c2, d_a2, nullptr, d_a1))) return rc;
     BnBwdSide s1{b.raw1, b.b1.mean, b.b1.invstd, b.b1.scale, b.b1.shift};
-    if ((rc = launch_bn_bwd(st, d_a1, b.a1, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
+    if ((rc = launch_bn_bwd(st, d_a1, nullptr, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
                             net->G + b.b1.b_off, nullptr, nullptr, d_a1, nullptr, nullptr, net->red_scratch))) return rc;
     // conv1 (+ identity / downsample branch)
     if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
