@@ -209,7 +209,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     size_t max_slab = 0;
     {
         int sp, pps; size_t wsb;
-        wgrad_plan(wb, 224, (int)N * net->stem_h * net->stem_w, 768, &sp, &pps, &wsb);
+        wgrad_plan(wb, 224, (int)N * net->stem_h * net->stem_w, 512, &sp, &pps, &wsb);
         max_slab = wsb;
     }
     for (auto& b : net->blocks) {
@@ -230,7 +230,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             const int P = (int)N * c->hout * c->wout;
             max_stat = std::max(max_stat, (size_t)igemm_conv_stat_tiles(c->cout, P) * c->cout * 2 * 4);
             int sp, pps; size_t wsb;
-            wgrad_plan(c->cout, c->r * c->s * c->cin, P, 768, &sp, &pps, &wsb);
+            wgrad_plan(c->cout, c->r * c->s * c->cin, P, 512, &sp, &pps, &wsb);
             max_slab = std::max(max_slab, wsb);
             max_act = std::max(max_act, (size_t)P * c->cout * 2);
             max_act = std::max(max_act, N * c->hin * c->win * c->cin * 2);
@@ -356,7 +356,7 @@ int conv_wgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* 
     a.Cm = c.cout; a.P = net->N * c.hout * c.wout; a.Ntot = c.r * c.s * c.cin;
     a.g = conv_geom(c, 0);
     size_t wsb;
-    wgrad_plan(a.Cm, a.Ntot, a.P, 768, &a.splits, &a.pix_per_split, &wsb);
+    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb);
     return launch_igemm_wgrad(st, a, net->G + c.w_off, 0);
 }
 
@@ -502,7 +502,7 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
             a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w; a.Ntot = 224;
             a.g = stem_geom(net);
             size_t wsb;
-            wgrad_plan(a.Cm, a.Ntot, a.P, 768, &a.splits, &a.pix_per_split, &wsb);
+            wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb);
             if ((rc = launch_igemm_wgrad(st, a, net->stem_dw_pad, 0))) return rc;
             if ((rc = launch_stem_unpack_wgrad(st, net->stem_dw_pad, net->stem.cout, net->G + net->stem.w_off))) return rc;
         }
