@@ -130,12 +130,14 @@ struct WeightLoader {
 };
 
 // Shared epilogue: bf16 store of O (+ residual) and the per-tile BatchNorm partial statistics.
-template <class Cfg>
-__device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)[Cfg::FM][Cfg::FN], int tm, int tn, uint16_t* smem) {
-    constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    int mb, nb;
-    acc_coords<Cfg>(mb, nb);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <int FM_, int FN_> struct EpiShape { static constexpr int FM = FM_, FN = FN_; };
+// Generic over the block shape: TM x TN tile, WNW waves along n, NT threads; this wave sits at (wm, wn) and owns an
+// (FM*16) x (FN*16) sub-tile.
+template <int TM, int TN, int FM_, int FN_, int WNW, int NT>
+__device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&acc)[FM_][FN_], int tm, int tn, uint16_t* smem, int wm, int wn) {
+    using Cfg = EpiShape<FM_, FN_>;
+    const int lane = threadIdx.x & 63;
+    const int mb = wm * (FM_ * 16) + (lane >> 4) * 4, nb = wn * (FN_ * 16) + (lane & 15);
     // ---- store O (+ residual) ----
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
@@ -175,8 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)
     // ---- BatchNorm partial statistics: per channel sum / sumsq over this tile's pixels ----
     if (a.stats) {
         __syncthreads();                           // mainloop LDS reads are done: reuse smem
-        float* red = reinterpret_cast<float*>(smem);   // [2 (wn)][TM][2]
-        const int wn = wave & 1;
+        float* red = reinterpret_cast<float*>(smem);   // [WNW (wn)][TM][2]
 #pragma unroll
         for (int i = 0; i < Cfg::FM; ++i) {
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -199,15 +200,22 @@ __device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)
             }
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < TM; t += 256) {
+        for (int t = threadIdx.x; t < TM; t += NT) {
             const int c = tm * TM + t;
             if (c < a.Cm) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WNW; ++w) { s1 += red[(w * TM + t) * 2]; s2 += red[(w * TM + t) * 2 + 1]; }
                 float* dst = a.stats + ((size_t)tn * a.Cm + c) * 2;
-                dst[0] = red[t * 2] + red[(TM + t) * 2];
-                dst[1] = red[t * 2 + 1] + red[(TM + t) * 2 + 1];
+                dst[0] = s1; dst[1] = s2;
             }
         }
     }
+}
+template <class Cfg>
+__device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)[Cfg::FM][Cfg::FN], int tm, int tn, uint16_t* smem) {
+    const int wave = threadIdx.x >> 6;
+    conv_epilogue_g<Cfg::TM, Cfg::TN, Cfg::FM, Cfg::FN, 2, 256>(a, acc, tm, tn, smem, wave >> 1, wave & 1);
 }
 
 template <int TM, int TN, bool IN_BN>
@@ -252,6 +260,7 @@ __device__ __forceinline__ void dma_wait() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else static_assert(N == 0, "unsupported DMA count");
 }
 
@@ -371,6 +380,121 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     __syncthreads();
 
     conv_epilogue<Cfg>(a, acc, tm, tn, smem);
+}
+
+// Wave-grid variant for the large layers: WM x WN waves, each owning a 64 x 64 sub-tile (same per-wave code and register
+// budget as the 128 x 128 kernel), block tile (64*WM) x (64*WN).  256 x 256 with 16 waves halves the L2->LDS bytes per
+// FLOP (measured limiter of the 128 x 128 kernel: ~47 GB/s per CU of operand traffic at 0.8 PFLOP/s) and leaves room
+// for a 4-deep LDS ring (3 k-tiles in flight) at one block per CU.
+template <int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN, NT = NW * 64;
+    constexpr int A_BLK = TM / 16 / NW, B_BLK = TN / 16 / NW, NDMA = A_BLK + B_BLK;
+    constexpr int A_ELEMS = TM * 32, B_ELEMS = TN * 32, STAGE_ELEMS = A_ELEMS + B_ELEMS;
+    constexpr int AHEAD = NSTAGE - 1;
+    static_assert(TM % (16 * NW) == 0 && TN % (16 * NW) == 0, "DMA blocks must divide evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const GatherGeom g = a.g;
+    const int K = g.R * g.S * g.Ck;
+    const int ktiles = K >> 5;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+    const int r_in = lane >> 2;
+    const int kc = (lane & 3) ^ lds_swz(r_in);
+    uint32_t a_off[A_BLK];
+#pragma unroll
+    for (int i = 0; i < A_BLK; ++i) {
+        const int m = tm * TM + 16 * (wave + NW * i) + r_in;
+        a_off[i] = (m < a.Cm) ? (uint32_t)(m * K + kc * 8) * 2u : DMA_OOB;
+    }
+    int b_pix[B_BLK], b_h0[B_BLK], b_w0[B_BLK];
+#pragma unroll
+    for (int i = 0; i < B_BLK; ++i) {
+        const int p = tn * TN + 16 * (wave + NW * i) + r_in;
+        int n = 0, ho = 0, wo = 0;
+        const bool ok = p < a.P;
+        if (ok) decode_pixel(g, p, n, ho, wo);
+        if (g.mode == 0) { b_h0[i] = ho * g.stride - g.pad; b_w0[i] = wo * g.stride - g.pad; }
+        else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
+        if (!ok) b_h0[i] = -0x40000000;
+        b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;
+    }
+    int kr = 0, ks = 0, kc0 = 0;
+    auto issue = [&](int stage) {
+        uint16_t* sa = smem + stage * STAGE_ELEMS;
+        uint16_t* sb = sa + A_ELEMS;
+        const int kbase = ((kr * g.S + ks) * g.Ck + kc0) * 2;
+#pragma unroll
+        for (int i = 0; i < A_BLK; ++i) {
+            const uint32_t off = (a_off[i] == DMA_OOB) ? DMA_OOB : a_off[i] + (uint32_t)kbase;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (wave + NW * i) * 512), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_BLK; ++i) {
+            int hi, wi;
+            bool ok = true;
+            if (g.mode == 0) { hi = b_h0[i] + kr; wi = b_w0[i] + ks; }
+            else {
+                const int th = b_h0[i] - kr, tw = b_w0[i] - ks;
+                ok = (th >= 0) && (tw >= 0);
+                if (g.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                else { hi = th; wi = tw; }
+            }
+            ok = ok && ((unsigned)hi < (unsigned)g.Hin) && ((unsigned)wi < (unsigned)g.Win);
+            const uint32_t off = ok ? (uint32_t)(b_pix[i] + hi * g.row_pitch + wi * g.pix_pitch + kc0) * 2u : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + NW * i) * 512), 16, off, 0, 0, 0);
+        }
+        kc0 += 32;
+        if (kc0 == g.Ck) { kc0 = 0; if (++ks == g.S) { ks = 0; ++kr; } }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frag_off = (lane & 15) * 32 + (((lane >> 4) ^ lds_swz(lane & 15)) << 3);
+    const int a_row0 = wm * 64, b_row0 = wn * 64;
+    // prologue: AHEAD tiles in flight, wait for the first
+    int issued = 0;
+    for (; issued < AHEAD && issued < ktiles; ++issued) issue(issued);
+    if (issued == 1) dma_wait<0>();
+    else if (issued == 2) dma_wait<NDMA>();
+    else dma_wait<2 * NDMA>();
+    __builtin_amdgcn_s_barrier();
+    int st_cur = 0, st_fill = AHEAD % NSTAGE;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const bool more = kt + AHEAD < ktiles;
+        if (more) issue(st_fill);
+        const uint16_t* sa = smem + st_cur * STAGE_ELEMS;
+        const uint16_t* sb = sa + A_ELEMS;
+        bf16x8_t fa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + (a_row0 + i * 16) * 32 + frag_off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(sb + (b_row0 + j * 16) * 32 + frag_off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+        }
+        // retire tile kt+1: everything but the youngest min(AHEAD-1, remaining) tiles must have landed
+        const int left = ktiles - 1 - kt;                    // tiles after this one
+        int inflight_after = left < AHEAD ? left : AHEAD;      // tiles issued and not yet multiplied (excl. current)
+        // allowed still-in-flight tiles = inflight_after - 1 (tile kt+1 must be complete)
+        if (inflight_after <= 1) dma_wait<0>();
+        else if (inflight_after == 2) dma_wait<NDMA>();
+        else dma_wait<2 * NDMA>();
+        __builtin_amdgcn_s_barrier();
+        st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
+        st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
+    }
+    __syncthreads();
+    conv_epilogue_g<TM, TN, 4, 4, WN, NT>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -658,6 +782,32 @@ using namespace dali;
 
 namespace dali {
 
+// Tile configuration per problem (measured on MI355X, scripts/bench_convs.py): 64x256 for <= 64 output channels;
+// 256x256 / 16 waves / 4-deep ring when both K and Cm are large (operand traffic per FLOP halves: +25..36 % on the
+// layer4 3x3); 128x256 / 8 waves for Cm = 256 with K >= 1024; 128x128 / 4 waves otherwise (small K: prologue-bound).
+enum ConvCfg { CONV_NARROW = 0, CONV_128 = 1, CONV_128x256 = 2, CONV_256x256 = 3 };
+static int conv_cfg_override() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("DALI_CONV_CFG"); v = e ? atoi(e) : -1; }
+    return v;
+}
+int conv_pick_cfg(int Cm, int P, int K) {
+    if (Cm <= 64) return CONV_NARROW;
+    const int ov = conv_cfg_override();
+    if (ov == 0 || ov == 1) return CONV_128;
+    if (ov == 4) return Cm >= 256 ? CONV_256x256 : CONV_128;
+    if (ov == 6) return Cm >= 256 ? CONV_128x256 : CONV_128;
+    if (K >= 1024 && P >= 16384) {
+        if (Cm >= 512) return CONV_256x256;
+        if (Cm >= 256) return CONV_128x256;
+    }
+    return CONV_128;
+}
+int igemm_conv_stat_tiles(int Cm, int P, int K) {
+    const int c = conv_pick_cfg(Cm, P, K);
+    return (c == CONV_128) ? (P + 127) / 128 : (P + 255) / 256;
+}
+
 // Host-side launchers shared with the net plan (resnet_plan.hip).
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     const bool in_bn = a.in_scale != nullptr;
@@ -668,8 +818,12 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     // the LDS-DMA kernel addresses both tensors with 32-bit byte offsets through buffer descriptors
     const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
     const bool dma_ok = !in_bn && x_bytes < 0x7ff00000ll && (long long)a.Cm * a.g.R * a.g.S * a.g.Ck * 2 < 0x7ff00000ll;
-    static int cfg_override = -2;
-    if (cfg_override == -2) { const char* e = getenv("DALI_CONV_CFG"); cfg_override = e ? atoi(e) : -1; }
+    const int K = a.g.R * a.g.S * a.g.Ck;
+    const int cfg = conv_pick_cfg(a.Cm, a.P, K);
+    if (!dma_ok && !in_bn && a.stats && (cfg == CONV_128x256 || cfg == CONV_256x256)) {
+        set_error("conv: tensors beyond 2 GiB are not supported together with the BatchNorm statistics epilogue");
+        return DALI_ERR_LIMIT;
+    }
     if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
@@ -677,28 +831,30 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<64, 256, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<64, 256, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
-    } else if (dma_ok && ((cfg_override == 2 || cfg_override == 3) && a.Cm >= 256)) {
-        using Cfg = GemmCfg<256, 128, 1, 1, 1>;
-        const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 127) / 128;
-        const int grid = xcd_tile_grid(tiles_m, tiles_n);
-        if (cfg_override == 2) hipLaunchKernelGGL((igemm_conv_dma_kernel<256, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
-        else {
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_dma_kernel<256, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES / 2 * 3));
-            hipLaunchKernelGGL((igemm_conv_dma_kernel<256, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
-        }
+    } else if (!in_bn && dma_ok && cfg == CONV_256x256) {
+        static bool attr_set = false;
+        const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
+        const int lds = (256 + 256) * 32 * 2 * 4;
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_conv_wg_kernel<4, 4, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+    } else if (!in_bn && dma_ok && cfg == CONV_128x256) {
+        static bool attr_set = false;
+        const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
+        const int lds = (128 + 256) * 32 * 2 * 3;
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else {
         using Cfg = GemmCfg<128, 128, 1, 1, 1>;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<128, 128, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
-        else if (dma_ok && cfg_override == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok && conv_cfg_override() == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
     }
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-int igemm_conv_stat_tiles(int Cm, int P) { return Cm <= 64 ? (P + 255) / 256 : (P + 127) / 128; }   // every wide config uses TN = 128
 
 // Chooses the split count so that the grid has ~target blocks; returns slab bytes through *ws_bytes.
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes) {
@@ -764,7 +920,11 @@ extern "C" int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, c
     return launch_igemm_conv((hipStream_t)stream, a);
 }
 
-extern "C" int dali_conv2d_stat_tiles(int cout, int n, int ho, int wo) { return igemm_conv_stat_tiles(cout, n * ho * wo); }
+extern "C" int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int n, int ho, int wo, int fused_operand) {
+    // the fused-operand (register-staged) kernels always use 128-pixel tiles for cout > 64
+    if (fused_operand && cout > 64) return (n * ho * wo + 127) / 128;
+    return igemm_conv_stat_tiles(cout, n * ho * wo, r * s * cin);
+}
 
 extern "C" int dali_conv2d_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, uint16_t* dx,
                                  const uint16_t* residual, int n, int h, int wd, int cin, int cout, int r, int s,

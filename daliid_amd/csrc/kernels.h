@@ -46,7 +46,7 @@ struct BnBwdSide { const uint16_t* raw; const float* mean; const float* invstd; 
 
 // conv.hip
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a);
-int igemm_conv_stat_tiles(int Cm, int P);
+int igemm_conv_stat_tiles(int Cm, int P, int K);
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes);
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
 

@@ -204,7 +204,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     reserve(net, a, net->pool0, N * net->pool_h * net->pool_w * wb * 2);
     reserve(net, a, net->pool_arg, N * net->pool_h * net->pool_w * wb);
     reserve_bn(net, a, net->stem_bn);
-    size_t max_act = raw0_bytes, max_stat = (size_t)igemm_conv_stat_tiles(wb, (int)N * net->stem_h * net->stem_w) * wb * 2 * 4;
+    size_t max_act = raw0_bytes, max_stat = (size_t)igemm_conv_stat_tiles(wb, (int)N * net->stem_h * net->stem_w, 224) * wb * 2 * 4;
     size_t max_bwd_partial = bn_bwd_partial_floats((int)N * net->stem_h * net->stem_w, wb, false) * 4;
     size_t max_slab = 0;
     {
@@ -228,7 +228,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             if (!c) continue;
             reserve(net, a, c->wt_bf16, (size_t)c->cin * c->r * c->s * c->cout * 2);
             const int P = (int)N * c->hout * c->wout;
-            max_stat = std::max(max_stat, (size_t)igemm_conv_stat_tiles(c->cout, P) * c->cout * 2 * 4);
+            max_stat = std::max(max_stat, (size_t)igemm_conv_stat_tiles(c->cout, P, c->r * c->s * c->cin) * c->cout * 2 * 4);
             int sp, pps; size_t wsb;
             wgrad_plan(c->cout, c->r * c->s * c->cin, P, 512, &sp, &pps, &wsb);
             max_slab = std::max(max_slab, wsb);
@@ -345,7 +345,7 @@ int conv_bn_fwd(dali_resnet* net, hipStream_t st, const Conv& c, Bn& out_bn, con
     a.g = conv_geom(c, 0);
     int rc = launch_igemm_conv(st, a);
     if (rc) return rc;
-    if (training) return bn_train(net, st, out_bn, igemm_conv_stat_tiles(a.Cm, a.P), (double)a.P);
+    if (training) return bn_train(net, st, out_bn, igemm_conv_stat_tiles(a.Cm, a.P, a.g.R * a.g.S * a.g.Ck), (double)a.P);
     return bn_eval(net, st, out_bn);
 }
 
@@ -394,7 +394,7 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
         a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w;
         a.g = stem_geom(net);
         if ((rc = launch_igemm_conv(st, a))) return rc;
-        rc = tr ? bn_train(net, st, net->stem_bn, igemm_conv_stat_tiles(a.Cm, a.P), (double)a.P) : bn_eval(net, st, net->stem_bn);
+        rc = tr ? bn_train(net, st, net->stem_bn, igemm_conv_stat_tiles(a.Cm, a.P, 224), (double)a.P) : bn_eval(net, st, net->stem_bn);
         if (rc) return rc;
     }
     if ((rc = launch_maxpool_bn_fwd(st, net->raw0, net->stem_bn.scale, net->stem_bn.shift, net->N, net->stem_h, net->stem_w, net->stem.cout,
