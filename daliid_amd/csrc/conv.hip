@@ -733,6 +733,132 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
         }
 }
 
+// wgrad, wave-grid variant: WM x WN waves of 64 x 64 sub-tiles; the (64*WM) x (64*WN) block tile is held as (TM+TN)/128
+// swizzled [32 px][128 ch] LDS images per stage (same image / tr-read scheme as above), NSTAGE-deep ring.
+template <int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+    constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN;
+    constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128;
+    constexpr int NBLK = NIMG * 8 / NW;                 // 1 KiB DMA blocks per wave per k-step
+    constexpr int AHEAD = NSTAGE - 1;
+    static_assert((NIMG * 8) % NW == 0 && TM % 128 == 0 && TN % 128 == 0, "unsupported wave grid");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles = tiles_m * tiles_n;
+    const int work = tiles * a.splits, per_xcd = (work + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= work) return;
+    const int ks = item / tiles, tile = item - ks * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const GatherGeom g = a.g;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+    // this wave's DMA blocks: q = wave + NW*i -> image q>>3, block q&7 (rows 4*(q&7) + lane>>4); (q&7) is the same for every i
+    const int r_in = lane >> 4, ps = lane & 15;
+    const int blk = wave & 7;
+    const int c16 = ((((ps >> 1) ^ wg_swz(4 * blk + r_in)) << 1) | (ps & 1));
+    // per-block operand column state
+    bool is_a[NBLK], col_ok[NBLK];
+    int col[NBLK], tap_r[NBLK], tap_s[NBLK], img_of[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int q = wave + NW * i, img = q >> 3;
+        img_of[i] = img;
+        is_a[i] = img < NIMG_A;
+        if (is_a[i]) {
+            col[i] = m0 + img * 128 + c16 * 8;
+            col_ok[i] = col[i] < a.Cm;
+            tap_r[i] = tap_s[i] = 0;
+        } else {
+            const int bn = n0 + (img - NIMG_A) * 128 + c16 * 8;
+            col_ok[i] = bn < a.Ntot;
+            const int tap = col_ok[i] ? bn / g.Ck : 0;
+            col[i] = bn - tap * g.Ck;
+            tap_r[i] = tap / g.S; tap_s[i] = tap - tap_r[i] * g.S;
+        }
+    }
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.P, p_begin + a.pix_per_split);
+    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+
+    auto issue = [&](int kt, int stage) {
+        uint16_t* base = smem + stage * NIMG * IMG;
+        const int p = p_begin + kt * 32 + 4 * blk + r_in;
+        int n = 0, ho = 0, wo = 0;
+        const bool pok = p < p_end;
+        if (pok) decode_pixel(g, p, n, ho, wo);
+        const int pix_base = (int)((long long)n * g.img_pitch);
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            uint32_t off = DMA_OOB;
+            if (pok && col_ok[i]) {
+                if (is_a[i]) off = (uint32_t)(p * a.Cm + col[i]) * 2u;
+                else {
+                    const int hi = ho * g.stride - g.pad + tap_r[i], wi = wo * g.stride - g.pad + tap_s[i];
+                    if ((unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win)
+                        off = (uint32_t)(pix_base + hi * g.row_pitch + wi * g.pix_pitch + col[i]) * 2u;
+                }
+            }
+            uint16_t* dst = base + img_of[i] * IMG + blk * 512;
+            if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (ksteps > 0) {
+        int issued = 0;
+        for (; issued < AHEAD && issued < ksteps; ++issued) issue(issued, issued);
+        if (issued == 1) dma_wait<0>();
+        else if (issued == 2) dma_wait<NBLK>();
+        else dma_wait<2 * NBLK>();
+        __builtin_amdgcn_s_barrier();
+        int st_cur = 0, st_fill = AHEAD % NSTAGE;
+        for (int kt = 0; kt < ksteps; ++kt) {
+            if (kt + AHEAD < ksteps) issue(kt + AHEAD, st_fill);
+            const uint16_t* sa = smem + st_cur * NIMG * IMG + (wm >> 1) * IMG;
+            const uint16_t* sb = smem + st_cur * NIMG * IMG + (NIMG_A + (wn >> 1)) * IMG;
+            bf16x8_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, (wm & 1) * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t fb = tr_frag(sb, (wn & 1) * 4 + j, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+            }
+            const int left = ksteps - 1 - kt;
+            const int inflight_after = left < AHEAD ? left : AHEAD;
+            if (inflight_after <= 1) dma_wait<0>();
+            else if (inflight_after == 2) dma_wait<NBLK>();
+            else dma_wait<2 * NBLK>();
+            __builtin_amdgcn_s_barrier();
+            st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
+            st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
+        }
+    }
+    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
+                if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
+            }
+        }
+}
+
 // out[e] (= or +=) sum_s partial[s][e]; fixed summation tree => deterministic.  HBM-bound.
 // A block covers 256/SL float4 chunks; SL "split lanes" share the slabs of one chunk (s = lane, lane+SL, ...) and are
 // combined through LDS, so tiny outputs with hundreds of slabs (layer1's 64x64 weights) still use many threads.
@@ -857,11 +983,22 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
 }
 
 // Chooses the split count so that the grid has ~target blocks; returns slab bytes through *ws_bytes.
+// 0: 128x128 (4 waves); 1: 256x256 (16 waves, 4-deep ring) for the large weight matrices
+int wgrad_pick_cfg(int Cm, int Ntot) {
+    static int ov = -2;
+    if (ov == -2) { const char* e = getenv("DALI_WGRAD_CFG"); ov = e ? atoi(e) : -1; }
+    if (ov >= 0) return (ov == 1 && Cm >= 256 && Ntot >= 256) ? 1 : 0;
+    // measured (r01): the 16-wave tile wins on the wide 1x1 layers of layer4 and loses on the 3x3 (Ntot = 9 Cin) ones
+    return (Cm >= 512 && Ntot >= 512 && Ntot <= 2048) ? 1 : 0;
+}
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes) {
     static int target_override = -2;
     if (target_override == -2) { const char* e = getenv("DALI_WGRAD_TARGET"); target_override = e ? atoi(e) : -1; }
     if (target_override > 0) target_blocks = target_override;
-    const int tiles = ((Cm + 127) / 128) * ((Ntot + 127) / 128);
+    const int big = wgrad_pick_cfg(Cm, Ntot);
+    const int T = big ? 256 : 128;
+    if (big) target_blocks = 256;                   // one 16-wave block per CU
+    const int tiles = ((Cm + T - 1) / T) * ((Ntot + T - 1) / T);
     int sp = (target_blocks + tiles - 1) / tiles;
     const int max_sp = (P + 255) / 256;              // at least 8 k-steps per block
     if (sp > max_sp) sp = max_sp;
@@ -880,7 +1017,13 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const int grid = tiles_m * tiles_n * a.splits;
     const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
     const bool dma_ok = x_bytes < 0x7ff00000ll && (long long)a.P * a.Cm * 2 < 0x7ff00000ll;
-    if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
+    if (!a.in_scale && dma_ok && wgrad_pick_cfg(a.Cm, a.Ntot) == 1) {
+        static bool attr_set = false;
+        const int tm2 = (a.Cm + 255) / 256, tn2 = (a.Ntot + 255) / 256;
+        const int lds = 4 * 4 * 32 * 128 * 2;       // 4 stages x 4 images x 8 KiB
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_wgrad_wg_kernel<4, 4, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds, st, args, tm2, tn2);
+    } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     DALI_LAUNCH_CHECK();
