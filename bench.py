@@ -121,6 +121,17 @@ def bench_distance(args, world, rank):
             "roofline": roofline, "cpu_baseline": cpu}
 
 
+def committed_traffic(which):
+    """HBM bytes per step of the GEMM kernels from the committed PMC pass (profiles/*_pmc_traffic.json: rocprofv3 --pmc
+    in its own run, corrected as MI355X_MICROARCH.md prescribes); None when no such profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % which)
+    try:
+        with open(path) as f:
+            return json.load(f)["gemm_kernels_hbm_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
@@ -266,12 +277,33 @@ def bench_train(args, world, rank):
     gpu_ms = ev0.elapsed_time(ev1) / args.steps
     ms_step = dt / args.steps * 1e3
     ips = world * batch / (dt / args.steps)
-    tflops = batch * gflop_img / 1e3 / (gpu_ms * 1e-3)
-    roofline = {"kernel": "train step (all MFMA GEMM kernels: igemm_conv_dma_kernel / igemm_wgrad_dma_kernel%s)" % (" / attention" if vit else ""),
-                "bound": "mfma",
-                "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                "note": "algorithmic GEMM FLOPs (%.2f GFLOP/img) / device time of the whole step between HIP events on the launch stream" % gflop_img}
+    step_tflops = batch * gflop_img / 1e3 / (gpu_ms * 1e-3)
+    # Dominant kernel family = the implicit-GEMM MFMA kernels (igemm_conv_* forward/dgrad + igemm_wgrad_*).  Their
+    # launch durations are measured live: the same steps again with every such launch bracketed by HIP events on the
+    # launch stream (dali_gemm_profile_*).  achieved = algorithmic GEMM FLOPs of those launches / their summed duration.
+    from daliid_amd._lib import GemmProfile
+    psteps = min(args.steps, 3)
+    with GemmProfile(max_launches=4096 * psteps) as gp:
+        for _ in range(psteps):
+            step()
+    barrier_sync(world)
+    k_ms = sum(gp.ms) / psteps
+    k_launches = sum(gp.launches) // psteps
+    alg_flops = batch * gflop_img * 1e9
+    tflops = alg_flops / (k_ms * 1e-3) / 1e12
+    traffic = committed_traffic("vit" if vit else "train")
+    roofline = {"kernel": "igemm_conv_* + igemm_wgrad_* (implicit-GEMM MFMA kernels%s)" % ("; attention kernels not included" if vit else ""),
+                "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "launches_per_step": int(k_launches), "kernel_ms_per_step": round(k_ms, 3),
+                "avg_launch_us": round(k_ms * 1e3 / max(k_launches, 1), 2),
+                "by_class_ms_per_step": {"conv_fwd_dgrad": round(gp.ms[0] / psteps, 3), "wgrad": round(gp.ms[1] / psteps, 3)},
+                "launched_gemm_tflop_per_step": round(sum(gp.flops) / psteps / 1e12, 4),
+                "whole_step": {"achieved": round(step_tflops, 2), "frac": round(step_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                               "device_ms": round(gpu_ms, 3)},
+                "note": "achieved = algorithmic GEMM FLOPs per step (%.3f GFLOP/img x %d) / summed duration of the GEMM kernel launches of "
+                        "one step, HIP events per launch on the launch stream; whole_step divides the same FLOPs by the device time of the "
+                        "entire step (BatchNorm, pools, heads, Adam, EMA included)" % (gflop_img, batch)}
     final = acc.cpu().numpy()
     log("GPU: %.3f ms/step (device %.3f ms), %.1f images/s" % (ms_step, gpu_ms, ips))
     cpu = None

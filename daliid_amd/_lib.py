@@ -66,6 +66,8 @@ _SIGNATURES = {
     "dali_proxy_kmax": [],
     "dali_adam_step": [c_void_p] * 6 + [ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p],
     "dali_ema_update": [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_float],
+    "dali_gemm_profile_begin": [c_void_p, c_int],
+    "dali_gemm_profile_end": [c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_resnet_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],
     "dali_resnet_destroy": [c_void_p],
     "dali_resnet_sizes": [c_void_p] + [c_void_p] * 6,
@@ -160,3 +162,23 @@ def ptr(t, dtype=None, name="tensor"):
     if dtype is not None and t.dtype != dtype:
         raise DaliError("%s must be %s, got %s" % (name, dtype, t.dtype))
     return c_void_p(t.data_ptr())
+
+
+class GemmProfile:
+    """Context manager over dali_gemm_profile_begin/_end (include/daliid.h): HIP-event timing of every MFMA GEMM
+    kernel launch issued inside the block.  ``.ms/.flops/.launches`` are 2-lists (0 = conv fwd+dgrad / linears,
+    1 = wgrad)."""
+
+    def __init__(self, max_launches=8192, device=None):
+        self._ctx, self._n = ctx(device), int(max_launches)
+        self.ms = self.flops = self.launches = None
+
+    def __enter__(self):
+        check(lib().dali_gemm_profile_begin(self._ctx, self._n), "dali_gemm_profile_begin")
+        return self
+
+    def __exit__(self, *exc):
+        ms, fl, ln = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_longlong * 2)()
+        check(lib().dali_gemm_profile_end(self._ctx, ms, fl, ln), "dali_gemm_profile_end")
+        self.ms, self.flops, self.launches = list(ms), list(fl), list(ln)
+        return False

@@ -15,6 +15,7 @@
 #include "gemm_tile.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <vector>
 
 namespace dali {
 
@@ -862,36 +863,49 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs 
 // out[e] (= or +=) sum_s partial[s][e]; fixed summation tree => deterministic.  HBM-bound.
 // A block covers 256/SL float4 chunks; SL "split lanes" share the slabs of one chunk (s = lane, lane+SL, ...) and are
 // combined through LDS, so tiny outputs with hundreds of slabs (layer1's 64x64 weights) still use many threads.
-template <int SL>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            size_t elems, int splits, int accumulate) {
-    constexpr int CH = 256 / SL;
-    __shared__ float4 red[256];
-    const int ch = threadIdx.x % CH, sl = threadIdx.x / CH;
-    const size_t i4 = ((size_t)blockIdx.x * CH + ch) * 4;
+// Split-K reduce: out[e] (+)= sum_k partial[k][e] in a fixed order.  One block covers 64 float4 chunks (1 KiB contiguous
+// per slab); wave w sums slabs w, w+WAVES, ... with 8 independent 16-byte loads in flight per lane (the pass is
+// latency-bound otherwise), then the waves' partial sums are added in wave order through LDS.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                  size_t elems, int splits, int accumulate) {
+    __shared__ float4 red[WAVES * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i4 = ((size_t)blockIdx.x * 64 + lane) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i4 < elems) {
-        if (i4 + 3 < elems) {
-            for (int k = sl; k < splits; k += SL) {
-                const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * elems + i4);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const bool vec = (elems & 3) == 0 && i4 + 3 < elems;      // slabs stay 16-byte aligned only then
+    if (vec) {
+        const float* base = partial + i4;
+        for (int k0 = w; k0 < splits; k0 += 8 * WAVES) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * WAVES;
+                v[u] = (k < splits) ? *reinterpret_cast<const float4*>(base + (size_t)k * elems) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        } else {
-            float* sp = reinterpret_cast<float*>(&s);
-            for (int k = sl; k < splits; k += SL)
-                for (size_t e = i4; e < elems; ++e) sp[e - i4] += partial[(size_t)k * elems + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
+    } else if (i4 < elems) {
+        float* sp = reinterpret_cast<float*>(&s);
+        for (int k = w; k < splits; k += WAVES)
+            for (size_t e = i4; e < elems; ++e) sp[e - i4] += partial[(size_t)k * elems + e];
     }
-    if (SL > 1) {
+    if (WAVES > 1) {
         red[threadIdx.x] = s;
         __syncthreads();
-        if (sl == 0) {
-            for (int k = 1; k < SL; ++k) { const float4 v = red[k * CH + ch]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        }
+        if (w == 0)
+            for (int k = 1; k < WAVES; ++k) { const float4 v = red[k * 64 + lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     }
-    if (sl == 0 && i4 < elems) {
-        const float* sp = reinterpret_cast<const float*>(&s);
-        for (int t = 0; t < 4 && i4 + t < elems; ++t) out[i4 + t] = accumulate ? out[i4 + t] + sp[t] : sp[t];
+    if (w == 0 && i4 < elems) {
+        if (vec) {
+            float4* o = reinterpret_cast<float4*>(out + i4);
+            if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+            *o = s;
+        } else {
+            const float* sp = reinterpret_cast<const float*>(&s);
+            for (int t = 0; t < 4 && i4 + t < elems; ++t) out[i4 + t] = accumulate ? out[i4 + t] + sp[t] : sp[t];
+        }
     }
 }
 
@@ -934,6 +948,30 @@ int igemm_conv_stat_tiles(int Cm, int P, int K) {
     return (c == CONV_128) ? (P + 127) / 128 : (P + 255) / 256;
 }
 
+
+// ---- live per-launch timing of the MFMA GEMM kernels (bench.py's roofline leg) ------------------------------------
+// Between dali_gemm_profile_begin and _end every conv / wgrad MFMA kernel launch is bracketed by two HIP events on
+// its own stream; _end synchronises and returns summed durations, launch counts and FLOPs per class
+// (0 = igemm_conv_* forward/dgrad, 1 = igemm_wgrad_*; the split-K reduce is not included).  Measurement aid only:
+// process-wide, not re-entrant, off by default.
+struct GemmProfiler {
+    std::vector<hipEvent_t> ev;        // 2 per launch
+    std::vector<int> cls;
+    std::vector<double> flops;
+    size_t used = 0, cap = 0;
+};
+static GemmProfiler* g_prof = nullptr;
+struct ProfScope {
+    hipStream_t st; bool on = false; size_t i = 0;
+    ProfScope(hipStream_t s, int cls, double flops) : st(s) {
+        if (!g_prof || g_prof->used >= g_prof->cap) return;
+        on = true; i = g_prof->used++;
+        g_prof->cls[i] = cls; g_prof->flops[i] = flops;
+        (void)hipEventRecord(g_prof->ev[2 * i], st);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(g_prof->ev[2 * i + 1], st); }
+};
+
 // Host-side launchers shared with the net plan (resnet_plan.hip).
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     const bool in_bn = a.in_scale != nullptr;
@@ -950,6 +988,8 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
         set_error("conv: tensors beyond 2 GiB are not supported together with the BatchNorm statistics epilogue");
         return DALI_ERR_LIMIT;
     }
+    {
+    ProfScope prof_scope(st, 0, 2.0 * a.Cm * (double)a.P * K);
     if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
@@ -977,6 +1017,7 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
         else if (dma_ok && conv_cfg_override() == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+    }
     }
     DALI_LAUNCH_CHECK();
     return DALI_OK;
@@ -1017,6 +1058,8 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const int grid = tiles_m * tiles_n * a.splits;
     const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
     const bool dma_ok = x_bytes < 0x7ff00000ll && (long long)a.P * a.Cm * 2 < 0x7ff00000ll;
+    {
+    ProfScope prof_scope(st, 1, 2.0 * a.Cm * (double)a.Ntot * a.P);
     if (!a.in_scale && dma_ok && wgrad_pick_cfg(a.Cm, a.Ntot) == 1) {
         static bool attr_set = false;
         const int tm2 = (a.Cm + 255) / 256, tn2 = (a.Ntot + 255) / 256;
@@ -1026,17 +1069,48 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
+    }
     DALI_LAUNCH_CHECK();
     const size_t elems = (size_t)a.Cm * a.Ntot, chunks = (elems + 3) / 4;
-    if (a.splits >= 128) hipLaunchKernelGGL(splitk_reduce_kernel<64>, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
-    else if (a.splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)((chunks + 15) / 16)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
-    else if (a.splits >= 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((chunks + 63) / 64)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
+    const unsigned rblocks = (unsigned)((chunks + 63) / 64);
+    if (a.splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(rblocks), dim3(1024), 0, st, a.partial, out, elems, a.splits, accumulate);
+    else if (a.splits >= 2) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, a.partial, out, elems, a.splits, accumulate);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 
 }  // namespace dali
+
+extern "C" int dali_gemm_profile_begin(dali_ctx* ctx, int max_launches) {
+    DALI_REQUIRE(ctx && max_launches > 0, "dali_gemm_profile_begin: bad argument");
+    DALI_REQUIRE(!g_prof, "dali_gemm_profile_begin: a profile is already open");
+    GemmProfiler* p = new GemmProfiler();
+    p->cap = (size_t)max_launches;
+    p->ev.resize(2 * p->cap); p->cls.resize(p->cap); p->flops.resize(p->cap);
+    for (auto& e : p->ev) DALI_HIP(hipEventCreate(&e));
+    g_prof = p;
+    return DALI_OK;
+}
+
+extern "C" int dali_gemm_profile_end(dali_ctx* ctx, double* total_ms, double* total_flops, long long* launches) {
+    DALI_REQUIRE(ctx && total_ms && total_flops && launches, "dali_gemm_profile_end: null argument");
+    DALI_REQUIRE(g_prof, "dali_gemm_profile_end: no open profile");
+    GemmProfiler* p = g_prof;
+    g_prof = nullptr;
+    for (int c = 0; c < 2; ++c) { total_ms[c] = 0; total_flops[c] = 0; launches[c] = 0; }
+    int rc = DALI_OK;
+    for (size_t i = 0; i < p->used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p->ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]) != hipSuccess) {
+            set_error("gemm_profile_end: event query failed"); rc = DALI_ERR_HIP; break;
+        }
+        total_ms[p->cls[i]] += ms; total_flops[p->cls[i]] += p->flops[i]; launches[p->cls[i]] += 1;
+    }
+    for (auto& e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+    return rc;
+}
 
 static int fill_geom(GatherGeom& g, int n_img, int Hin, int Win, int Ck, int Hout, int Wout, int R, int S, int stride, int pad, int mode) {
     g.Hout = Hout; g.Wout = Wout; g.Hin = Hin; g.Win = Win; g.Ck = Ck; g.R = R; g.S = S; g.stride = stride; g.pad = pad;

@@ -218,6 +218,15 @@ int dali_adam_step(dali_ctx* ctx, void* stream, float* params, const float* grad
 /* momentum = beta*momentum + (1-beta)*online  (train_encodersKIT.py:218-226), flat. */
 int dali_ema_update(dali_ctx* ctx, void* stream, float* momentum, const float* online, int64_t n, float beta);
 
+/* ---- measurement aid (bench.py roofline leg; no reference counterpart) ------------------------------- *
+ * Between _begin and _end every MFMA GEMM kernel launch of the conv / linear path (class 0: igemm_conv_*
+ * forward + dgrad, class 1: igemm_wgrad_*) is bracketed by two HIP events on the stream it is launched on.
+ * _end waits for them and returns, per class, the summed kernel duration [ms], the summed 2*M*N*K FLOPs
+ * and the launch count (arrays of 2).  Process-wide, not re-entrant; launches beyond max_launches are
+ * not recorded. */
+int dali_gemm_profile_begin(dali_ctx* ctx, int max_launches);
+int dali_gemm_profile_end(dali_ctx* ctx, double* total_ms, double* total_flops, long long* launches);
+
 /* ---- net plan: Encoders.ResNet50ReID forward / backward (Encoders.py:306-351) ------------------------ *
  * The plan owns topology + launch order; the caller owns storage: flat fp32 params / grads / BN running
  * statistics, and one byte arena (activations, bf16 weight images, scratch).  Tensor names and order follow

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; each in its own run, as MI355X_MICROARCH.md prescribes)
+into HBM bytes per train step, per kernel family.
+
+    python scripts/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_process> <out.json> [out.md]
+
+Corrections (guide, "HBM" section): rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests
+of wide (16 B/lane) streaming reads at 64 B, so reads are doubled; WRITE_SIZE is exact for 16 B/lane streaming stores."""
+import collections, csv, glob, json, sys
+
+
+def load(d, counter):
+    out = collections.defaultdict(lambda: [0.0, 0])
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    assert files, "no counter_collection.csv under " + d
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                k = r["Kernel_Name"]
+                out[k][0] += float(r["Counter_Value"]); out[k][1] += 1
+    return out
+
+
+def family(name):
+    if "igemm_conv" in name or "igemm_wgrad" in name:
+        return "gemm"
+    if "bn_" in name or "maxpool" in name or "head_pool" in name or "bn1d" in name:
+        return "batchnorm_pool"
+    if "splitk" in name or "reduce_partials" in name:
+        return "reductions"
+    return "other"
+
+
+def main():
+    fdir, wdir, steps, out_json = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+    fam = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        rd = fetch.get(k, [0, 0])[0] * 1024 * 2.0          # KiB -> B, x2 gfx950 correction
+        wr = write.get(k, [0, 0])[0] * 1024
+        n = max(fetch.get(k, [0, 0])[1], write.get(k, [0, 0])[1])
+        f = family(k)
+        fam[f][0] += rd; fam[f][1] += wr; fam[f][2] += n
+        rows.append((rd + wr, k, rd, wr, n))
+    res = {"steps_in_process": steps,
+           "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE KiB x1024",
+           "gemm_kernels_hbm_bytes_per_step": round((fam["gemm"][0] + fam["gemm"][1]) / steps),
+           "per_family_bytes_per_step": {f: {"read": round(v[0] / steps), "write": round(v[1] / steps), "launches": v[2] // steps}
+                                          for f, v in fam.items()},
+           "all_kernels_hbm_bytes_per_step": round(sum(v[0] + v[1] for v in fam.values()) / steps)}
+    json.dump(res, open(out_json, "w"), indent=1)
+    print(json.dumps(res))
+    if len(sys.argv) > 5:
+        with open(sys.argv[5], "w") as f:
+            f.write("| kernel | launches/step | read MB/step | write MB/step |\n|---|---:|---:|---:|\n")
+            for tot, k, rd, wr, n in sorted(rows, reverse=True)[:25]:
+                f.write("| `%s` | %.1f | %.1f | %.1f |\n" % (k[:90], n / steps, rd / steps / 1e6, wr / steps / 1e6))
+
+
+if __name__ == "__main__":
+    main()
