@@ -66,6 +66,8 @@ _SIGNATURES = {
     "dali_proxy_kmax": [],
     "dali_adam_step": [c_void_p] * 6 + [ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p],
     "dali_ema_update": [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_float],
+    "dali_class_targets": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                           c_void_p, c_void_p],
     "dali_gemm_profile_begin": [c_void_p, c_int],
     "dali_gemm_profile_end": [c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_resnet_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],

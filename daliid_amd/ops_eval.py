@@ -114,3 +114,25 @@ def rank_eval(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, return_p
     if return_per_query:
         return res + (o["ap"].cpu().numpy(), o["first_rank"].cpu().numpy())
     return res
+
+
+def class_targets(fvs, order, bounds, first_pick, num_proxies=5):
+    """Class centers + farthest-point proxies in one launch (train_encodersKIT.py:113-156, :252-284).
+    fvs [N,D] fp32 CUDA; order [N] int32 (rows sorted by identity), bounds [NC+1] int32, first_pick [NC] int32 (position
+    of the first proxy inside each identity's slice), all CUDA.
+    -> centers [NC,D], proxies [NC*num_proxies,D] (zero rows where an identity has fewer images), proxy_rows
+    [NC*num_proxies] int32 (row of fvs or -1), max_dist [NC]."""
+    assert fvs.dim() == 2 and fvs.is_contiguous()
+    n, d = fvs.shape
+    nc = bounds.numel() - 1
+    assert order.numel() == n and first_pick.numel() == nc
+    dev = fvs.device
+    centers = torch.empty(nc, d, device=dev, dtype=torch.float32)
+    proxies = torch.empty(nc * num_proxies, d, device=dev, dtype=torch.float32)
+    proxy_rows = torch.empty(nc * num_proxies, device=dev, dtype=torch.int32)
+    max_dist = torch.empty(nc, device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().dali_class_targets(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(fvs, torch.float32, "fvs"), n, d,
+                                              _lib.ptr(order, torch.int32, "order"), _lib.ptr(bounds, torch.int32, "bounds"), nc,
+                                              _lib.ptr(first_pick, torch.int32, "first_pick"), int(num_proxies), _lib.ptr(centers),
+                                              _lib.ptr(proxies), _lib.ptr(proxy_rows), _lib.ptr(max_dist)), "dali_class_targets")
+    return centers, proxies, proxy_rows, max_dist

@@ -20,39 +20,39 @@ torch.manual_seed(12)
 def selectProxiesByTriagulation(X, num_proxies=5):
     """train_encodersKIT.py:252-284: farthest-point sampling; first pick ``np.random.choice(n)``, then repeatedly the
     point whose minimum distance to the chosen set is largest (``argsort(...)[-1]``).
-    -> (indices LongTensor, max pairwise distance among the chosen)."""
-    dist = torch.cdist(X, X, p=2.0)
-    n = dist.shape[0]
-    running = torch.ones(n, device=X.device) * torch.max(dist)
-    proxies = [int(np.random.choice(n))]
-    num_proxies = min(num_proxies, n)
-    for j in range(num_proxies - 1):
-        running = torch.minimum(running, dist[proxies[j]])
-        proxies.append(int(torch.argsort(running, stable=True)[-1]))
-    proxies = torch.tensor(proxies, dtype=torch.long, device=X.device)
-    return proxies, torch.max(dist[proxies, :][:, proxies]).item()
+    -> (indices LongTensor, max pairwise distance among the chosen).  One launch of dali_class_targets."""
+    n = X.shape[0]
+    dev = X.device
+    first = torch.tensor([int(np.random.choice(n))], dtype=torch.int32, device=dev)
+    order = torch.arange(n, dtype=torch.int32, device=dev)
+    bounds = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    _, _, rows, max_dist = ops_eval.class_targets(X.contiguous().float(), order, bounds, first, num_proxies)
+    rows = rows[rows >= 0].long()
+    return rows, max_dist.item()
 
 
 def build_centers_and_proxies(fvs, labels, num_proxies=5):
     """train_encodersKIT.py:113-156 on device-resident features: per class, proxies by farthest-point sampling and
-    the center = mean of the un-normalised embeddings; both L2-normalised (no epsilon).
+    the center = mean of the un-normalised embeddings; both L2-normalised (no epsilon).  The per-class Python loop of
+    the reference becomes one kernel launch (one block per identity); the host only sorts the labels and draws the
+    first pick of every identity from numpy's global stream, one ``np.random.choice(n)`` per identity in label order as
+    the reference does (:257).
     -> (centers, centers_labels, all_proxies, proxies_labels, mean_max_distance)"""
     labels = np.asarray(labels)
-    centers_labels = np.unique(labels)
-    order = np.argsort(labels, kind="stable")
-    bounds = np.searchsorted(labels[order], centers_labels, side="left").tolist() + [len(labels)]
-    order_t = torch.from_numpy(order).to(fvs.device)
-    centers, all_proxies, proxies_labels, mean_max = [], [], [], 0.0
-    for ci, label in enumerate(centers_labels):
-        rows = fvs[order_t[bounds[ci]:bounds[ci + 1]]]
-        idx, max_dist = selectProxiesByTriagulation(rows, num_proxies=num_proxies)
-        mean_max += max_dist
-        all_proxies.append(rows[idx])
-        proxies_labels.append(np.array([label] * len(idx)))
-        centers.append(rows.mean(dim=0, keepdim=True))
-    centers = ops_eval.l2norm_rows(torch.cat(centers, 0).contiguous(), 0.0)
-    all_proxies = ops_eval.l2norm_rows(torch.cat(all_proxies, 0).contiguous(), 0.0)
-    return centers, centers_labels, all_proxies, np.concatenate(proxies_labels), mean_max / len(centers_labels)
+    centers_labels, counts = np.unique(labels, return_counts=True)
+    order = np.argsort(labels, kind="stable").astype(np.int32)
+    bounds = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+    first = np.array([np.random.choice(int(n)) for n in counts], dtype=np.int32)
+    dev = fvs.device
+    centers, proxies, rows, max_dist = ops_eval.class_targets(
+        fvs.contiguous().float(), torch.from_numpy(order).to(dev), torch.from_numpy(bounds).to(dev), torch.from_numpy(first).to(dev),
+        num_proxies)
+    per_class = np.minimum(counts, num_proxies)
+    if (per_class < num_proxies).any():                      # identities with fewer images than proxies: drop the empty slots
+        keep = torch.from_numpy((np.arange(num_proxies)[None, :] < per_class[:, None]).reshape(-1)).to(dev)
+        proxies = proxies[keep].contiguous()
+    proxies_labels = np.repeat(centers_labels, per_class)
+    return centers, centers_labels, proxies, proxies_labels, max_dist.mean().item()
 
 
 def collate_fn_PK(batch):

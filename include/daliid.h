@@ -218,6 +218,19 @@ int dali_adam_step(dali_ctx* ctx, void* stream, float* params, const float* grad
 /* momentum = beta*momentum + (1-beta)*online  (train_encodersKIT.py:218-226), flat. */
 int dali_ema_update(dali_ctx* ctx, void* stream, float* momentum, const float* online, int64_t n, float beta);
 
+/* ---- epoch targets: class centers + farthest-point proxies (train_encodersKIT.py:113-156, :252-284) -------- *
+ * fvs [n,d] fp32 un-normalised embeddings.  order [n]: row indices sorted by identity; bounds [n_classes+1]:
+ * identity c owns order[bounds[c] .. bounds[c+1]).  first_pick [n_classes]: position (0 .. n_c-1, within the
+ * identity's slice) of the first proxy -- the reference draws it with np.random.choice(n) (:257), so the host
+ * keeps that stream.  Outputs: centers [n_classes,d] = L2-normalised class means (:131-137); proxies
+ * [n_classes*num_proxies,d] = the chosen rows, L2-normalised (:139-141), zero rows where an identity has fewer than
+ * num_proxies images; proxy_rows [n_classes*num_proxies] = chosen row of fvs or -1; max_dist [n_classes] = largest
+ * pairwise distance among an identity's chosen rows (:278).  All pointers are device pointers.  Ties in the
+ * arg-max go to the highest row position (the reference's argsort(...)[-1] leaves them unspecified). */
+int dali_class_targets(dali_ctx* ctx, void* stream, const float* fvs, int n, int d, const int32_t* order,
+                       const int32_t* bounds, int n_classes, const int32_t* first_pick, int num_proxies,
+                       float* centers, float* proxies, int32_t* proxy_rows, float* max_dist);
+
 /* ---- measurement aid (bench.py roofline leg; no reference counterpart) ------------------------------- *
  * Between _begin and _end every MFMA GEMM kernel launch of the conv / linear path (class 0: igemm_conv_*
  * forward + dgrad, class 1: igemm_wgrad_*) is bracketed by two HIP events on the stream it is launched on.
