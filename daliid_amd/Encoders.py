@@ -84,6 +84,9 @@ class _NetFn(torch.autograd.Function):
         return None, torch.zeros_like(net._anchor), None
 
 
+_FEATURE_MODES = {"both": 0, "gap": 1, "gmp": 2}        # dali_feature in include/daliid.h
+
+
 class ResNet50ReID(nn.Module):
     """Encoders.ResNet50ReID (Encoders.py:306-351) on the HIP net plan."""
 
@@ -100,6 +103,7 @@ class ResNet50ReID(nn.Module):
         self._last_plan = None
         self._refreshed = (None, -1)
         self.grad_stage_hook = None          # callable(stage, begin, end) after each backward stage (DP all-reduce)
+        self.feature = "both"               # head pooling: "both" | "gap" | "gmp" (evaluateCleanATModels.py:249-256, :335-340)
         probe = self._plan(1, 32, 32)
         self.feat_dim = probe.feat_dim
         dev = self._device
@@ -215,6 +219,9 @@ class ResNet50ReID(nn.Module):
         plan = self._plan(x.shape[0], x.shape[2], x.shape[3])
         self._activate(plan)
         emb = torch.empty(x.shape[0], plan.feat_dim, device=self._device, dtype=torch.float32)
+        if self.feature not in _FEATURE_MODES:
+            raise _lib.DaliError("feature must be 'both', 'gap' or 'gmp' (got %r)" % (self.feature,))
+        _lib.check(_lib.lib().dali_resnet_set_feature(plan.h, _FEATURE_MODES[self.feature]), "dali_resnet_set_feature")
         _lib.check(_lib.lib().dali_resnet_forward(plan.h, _lib.stream_ptr(), _lib.ptr(x), int(training), _lib.ptr(emb)),
                    "dali_resnet_forward")
         if training:

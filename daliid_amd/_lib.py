@@ -44,8 +44,8 @@ _SIGNATURES = {
     "dali_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_int64, c_int] + [c_void_p] * 16,
     "dali_maxpool_bn_fwd": [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p],
     "dali_maxpool_bn_bwd": [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p],
-    "dali_head_pool_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
-    "dali_head_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dali_head_pool_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "dali_head_pool_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dali_bn1d_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                       c_void_p, c_void_p, c_void_p],
     "dali_bn1d_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6,
@@ -66,12 +66,15 @@ _SIGNATURES = {
     "dali_proxy_kmax": [],
     "dali_adam_step": [c_void_p] * 6 + [ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p],
     "dali_ema_update": [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_float],
+    "dali_pairdist_blend": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p],
     "dali_class_targets": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                            c_void_p, c_void_p],
     "dali_gemm_profile_begin": [c_void_p, c_int],
     "dali_gemm_profile_end": [c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_resnet_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],
     "dali_resnet_destroy": [c_void_p],
+    "dali_resnet_set_feature": [c_void_p, c_int],
     "dali_resnet_sizes": [c_void_p] + [c_void_p] * 6,
     "dali_resnet_tensor_info": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_resnet_stage_param_range": [c_void_p, c_int, c_void_p, c_void_p],

@@ -98,12 +98,21 @@ struct RowLoader {
     }
 };
 
+// Two-model fusion epilogue (evaluateCleanATModels.py:154-157): with `out` holding the first model's distances d1,
+//   out = (w1*d1 + w2*d2) / (w1 + w2),  w_m[q,g] = max(qmag_m[q], gmag_m[g])   (null magnitudes: weight 1 = the
+// "simple ensemble" (d1+d2)/2 of :126), d2 = this launch's 1 - q.g.
+struct PairBlend {
+    const float* qmag1; const float* gmag1;
+    const float* qmag2; const float* gmag2;
+    int on;
+};
+
 template <int NPROD>
 __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restrict__ Ghi, const uint16_t* __restrict__ Glo,
                                                        const uint16_t* __restrict__ Qhi, const uint16_t* __restrict__ Qlo,
                                                        const float* __restrict__ gsq, const float* __restrict__ qsq,
-                                                       int ng, int nq, int Kp, int metric, float* __restrict__ out,
-                                                       int tiles_m, int tiles_n) {
+                                                       int ng, int nq, int Kp, int metric, float* out,
+                                                       int tiles_m, int tiles_n, PairBlend blend) {
     using Cfg = typename PairCfg<NPROD>::type;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
@@ -143,6 +152,24 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
                 }
             }
             float* o = out + (size_t)q * ng + g0;
+            if (blend.on) {
+                const float qm1 = blend.qmag1 ? blend.qmag1[q] : 1.f, qm2 = blend.qmag2 ? blend.qmag2[q] : 1.f;
+                float prev[4];
+                if (vec_ok && g0 + 3 < ng) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(o);
+                    prev[0] = p4.x; prev[1] = p4.y; prev[2] = p4.z; prev[3] = p4.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) prev[r] = (g0 + r < ng) ? o[r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = (g0 + r < ng) ? g0 + r : g0;
+                    const float w1 = fmaxf(qm1, blend.gmag1 ? blend.gmag1[g] : 1.f);
+                    const float w2 = fmaxf(qm2, blend.gmag2 ? blend.gmag2[g] : 1.f);
+                    v[r] = (w1 * prev[r] + w2 * v[r]) / (w1 + w2);
+                }
+            }
             if (vec_ok && g0 + 3 < ng) {
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -362,7 +389,7 @@ extern "C" int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x,
 
 static int launch_pairdist(hipStream_t st, const uint16_t* ghi, const uint16_t* glo, const float* gsq,
                            const uint16_t* qhi, const uint16_t* qlo, const float* qsq, int nq, int ng, int Kp,
-                           int metric, bool split, float* out) {
+                           int metric, bool split, float* out, PairBlend blend = PairBlend{nullptr, nullptr, nullptr, nullptr, 0}) {
     const int tiles_m = (ng + 127) / 128, tiles_n = (nq + 127) / 128;
     const int grid = xcd_tile_grid(tiles_m, tiles_n);
     if (split) {
@@ -370,11 +397,11 @@ static int launch_pairdist(hipStream_t st, const uint16_t* ghi, const uint16_t* 
         DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_kernel<3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         hipLaunchKernelGGL(pairdist_kernel<3>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, ghi, glo, qhi, qlo, gsq, qsq, ng, nq,
-                           Kp, metric, out, tiles_m, tiles_n);
+                           Kp, metric, out, tiles_m, tiles_n, blend);
     } else {
         using Cfg = PairCfg<1>::type;
         hipLaunchKernelGGL(pairdist_kernel<1>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, ghi, ghi, qhi, qhi, gsq, qsq, ng, nq,
-                           Kp, metric, out, tiles_m, tiles_n);
+                           Kp, metric, out, tiles_m, tiles_n, blend);
     }
     DALI_LAUNCH_CHECK();
     return DALI_OK;
@@ -432,6 +459,37 @@ extern "C" int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const 
     rc = dali_pairdist_prepare(ctx, stream, Q, nq, d, normalize, qhi, qlo, sq + ng);
     if (rc != DALI_OK) return rc;
     return launch_pairdist((hipStream_t)stream, hi, lo, sq, qhi, qlo, sq + ng, nq, ng, Kp, metric, split, out);
+}
+
+extern "C" int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
+                                   int precision, int normalize, const float* q_mag_prev, const float* g_mag_prev,
+                                   const float* q_mag, const float* g_mag, float* inout) {
+    DALI_REQUIRE(ctx && Q && G && inout, "dali_pairdist_blend: null argument");
+    DALI_REQUIRE(nq >= 0 && ng >= 0 && d > 0, "dali_pairdist_blend: bad shape nq=%d ng=%d d=%d", nq, ng, d);
+    DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist_blend: bad precision %d", precision);
+    DALI_REQUIRE((q_mag_prev == nullptr) == (g_mag_prev == nullptr) && (q_mag == nullptr) == (g_mag == nullptr) &&
+                 (q_mag_prev == nullptr) == (q_mag == nullptr),
+                 "dali_pairdist_blend: the four magnitude vectors must be all set or all null");
+    DALI_REQUIRE((reinterpret_cast<uintptr_t>(inout) & 15) == 0, "dali_pairdist_blend: inout must be 16-byte aligned");
+    if (nq == 0 || ng == 0) return DALI_OK;
+    const int Kp = (d + 31) & ~31;
+    const bool split = precision == DALI_PREC_BF16X3;
+    const size_t rows = (size_t)nq + ng;
+    const size_t arr_bytes = align_up(rows * Kp * sizeof(uint16_t), 256);
+    const size_t total = arr_bytes * (split ? 2 : 1) + align_up(rows * sizeof(float), 256);
+    char* ws = static_cast<char*>(workspace(ctx, total));
+    if (!ws) return DALI_ERR_NOMEM;
+    uint16_t* hi = reinterpret_cast<uint16_t*>(ws);
+    uint16_t* lo = split ? reinterpret_cast<uint16_t*>(ws + arr_bytes) : nullptr;
+    float* sq = reinterpret_cast<float*>(ws + arr_bytes * (split ? 2 : 1));
+    uint16_t* qhi = hi + (size_t)ng * Kp;
+    uint16_t* qlo = lo ? lo + (size_t)ng * Kp : nullptr;
+    int rc = dali_pairdist_prepare(ctx, stream, G, ng, d, normalize, hi, lo, sq);
+    if (rc != DALI_OK) return rc;
+    rc = dali_pairdist_prepare(ctx, stream, Q, nq, d, normalize, qhi, qlo, sq + ng);
+    if (rc != DALI_OK) return rc;
+    return launch_pairdist((hipStream_t)stream, hi, lo, sq, qhi, qlo, sq + ng, nq, ng, Kp, DALI_METRIC_COSINE, split, inout,
+                           PairBlend{q_mag_prev, g_mag_prev, q_mag, g_mag, 1});
 }
 
 extern "C" int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat, const int32_t* q_pids,

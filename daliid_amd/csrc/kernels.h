@@ -80,8 +80,8 @@ int launch_maxpool_bn_fwd(hipStream_t st, const uint16_t* raw, const float* scal
 int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg, const uint16_t* raw, const float* mean, const float* invstd,
                           const float* scale, int N, int H, int W, int C, float* partial, float* coef, float* dgamma, float* dbeta,
                           uint16_t* draw, double* scratch);
-int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, float* f, int16_t* arg);
-int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, uint16_t* dx);
+int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, int mode, float* f, int16_t* arg);
+int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, int mode, uint16_t* dx);
 int launch_bn1d_fwd(hipStream_t st, const float* x, int N, int C, const float* gamma, const float* beta, float* rm, float* rv, int training,
                     float momentum, float eps, float* y, float* mean, float* invstd);
 int launch_bn1d_bwd(hipStream_t st, const float* x, const float* dy, int N, int C, const float* gamma, const float* mean, const float* invstd,

@@ -410,8 +410,9 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const uint16_
 
 // ------------------------------------------------------------------------------------------------
 // Head: f[n,c] = mean_hw x + max_hw x (Encoders.py:341-345), fp32 out, argmax kept for the backward.
+// mode: DALI_FEATURE_BOTH / _GAP (mean only) / _GMP (max only) = the `feature` switch of evaluateCleanATModels.py:335-340.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_pool_fwd_kernel(const uint16_t* __restrict__ x, int N, int HW, int C,
+__global__ __launch_bounds__(256) void head_pool_fwd_kernel(const uint16_t* __restrict__ x, int N, int HW, int C, int mode,
                                                              float* __restrict__ f, int16_t* __restrict__ arg) {
     const int cpr = C >> 3;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -429,12 +430,12 @@ __global__ __launch_bounds__(256) void head_pool_fwd_kernel(const uint16_t* __re
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        f[(size_t)n * C + cc + t] = sum[t] / (float)HW + best[t];
+        f[(size_t)n * C + cc + t] = (mode == DALI_FEATURE_GMP ? 0.f : sum[t] / (float)HW) + (mode == DALI_FEATURE_GAP ? 0.f : best[t]);
         arg[(size_t)n * C + cc + t] = (int16_t)bi[t];
     }
 }
 __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restrict__ df, const int16_t* __restrict__ arg, int N, int HW,
-                                                             int C, uint16_t* __restrict__ dx) {
+                                                             int C, int mode, uint16_t* __restrict__ dx) {
     const int cpr = C >> 3;
     const size_t total = (size_t)N * HW * cpr;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -444,7 +445,9 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
         float g[8], o[8];
         load8f(df + (size_t)n * C + cc, g);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] = g[t] / (float)HW + ((int)arg[(size_t)n * C + cc + t] == p ? g[t] : 0.f);
+        for (int t = 0; t < 8; ++t)
+            o[t] = (mode == DALI_FEATURE_GMP ? 0.f : g[t] / (float)HW) +
+                   ((mode != DALI_FEATURE_GAP && (int)arg[(size_t)n * C + cc + t] == p) ? g[t] : 0.f);
         *reinterpret_cast<uint4*>(dx + pix * C + cc) = pack8(o);
     }
 }
@@ -668,13 +671,13 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, float* f, int16_t* arg) {
-    hipLaunchKernelGGL(head_pool_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, st, x, N, HW, C, f, arg);
+int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, int mode, float* f, int16_t* arg) {
+    hipLaunchKernelGGL(head_pool_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, st, x, N, HW, C, mode, f, arg);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, uint16_t* dx) {
-    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, st, df, arg, N, HW, C, dx);
+int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, int mode, uint16_t* dx) {
+    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, st, df, arg, N, HW, C, mode, dx);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -774,15 +777,17 @@ extern "C" int dali_maxpool_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* 
                                  reinterpret_cast<double*>(ws + align_up(pf * 4, 256) + align_up((size_t)C * 12, 256)));
 }
 
-extern "C" int dali_head_pool_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, int n, int hw, int C, float* f, int16_t* arg) {
+extern "C" int dali_head_pool_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, int n, int hw, int C, int mode, float* f, int16_t* arg) {
     DALI_REQUIRE(ctx && x && f && arg, "dali_head_pool_fwd: null argument");
+    DALI_REQUIRE(mode >= DALI_FEATURE_BOTH && mode <= DALI_FEATURE_GMP, "dali_head_pool_fwd: bad feature mode %d", mode);
     DALI_REQUIRE(C % 8 == 0 && hw > 0 && hw < 32768, "dali_head_pool_fwd: bad shape");
-    return launch_head_pool_fwd((hipStream_t)stream, x, n, hw, C, f, arg);
+    return launch_head_pool_fwd((hipStream_t)stream, x, n, hw, C, mode, f, arg);
 }
-extern "C" int dali_head_pool_bwd(dali_ctx* ctx, void* stream, const float* df, const int16_t* arg, int n, int hw, int C, uint16_t* dx) {
+extern "C" int dali_head_pool_bwd(dali_ctx* ctx, void* stream, const float* df, const int16_t* arg, int n, int hw, int C, int mode, uint16_t* dx) {
     DALI_REQUIRE(ctx && df && arg && dx, "dali_head_pool_bwd: null argument");
+    DALI_REQUIRE(mode >= DALI_FEATURE_BOTH && mode <= DALI_FEATURE_GMP, "dali_head_pool_bwd: bad feature mode %d", mode);
     DALI_REQUIRE(C % 8 == 0 && hw > 0, "dali_head_pool_bwd: bad shape");
-    return launch_head_pool_bwd((hipStream_t)stream, df, arg, n, hw, C, dx);
+    return launch_head_pool_bwd((hipStream_t)stream, df, arg, n, hw, C, mode, dx);
 }
 extern "C" int dali_bn1d_fwd(dali_ctx* ctx, void* stream, const float* x, int n, int C, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, int training, float momentum, float eps, float* y, float* mean,

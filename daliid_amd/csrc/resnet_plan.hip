@@ -77,6 +77,7 @@ struct dali_resnet {
     uint16_t* cur_dy = nullptr;
     int64_t cur_dy_bytes = 0;
     bool fwd_training = false;
+    int feature_mode = DALI_FEATURE_BOTH;
 };
 
 namespace {
@@ -379,6 +380,13 @@ uint16_t* next_gbuf(dali_resnet* net, const uint16_t* avoid0, const uint16_t* av
 
 }  // namespace
 
+extern "C" int dali_resnet_set_feature(dali_resnet* net, int mode) {
+    DALI_REQUIRE(net, "dali_resnet_set_feature: null net");
+    DALI_REQUIRE(mode >= DALI_FEATURE_BOTH && mode <= DALI_FEATURE_GMP, "dali_resnet_set_feature: bad feature mode %d", mode);
+    net->feature_mode = mode;
+    return DALI_OK;
+}
+
 extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* images, int training, float* emb) {
     DALI_REQUIRE(net && net->P && images && emb, "dali_resnet_forward: null argument or net not bound");
     hipStream_t st = (hipStream_t)stream;
@@ -420,7 +428,7 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
         x = b.y;
     }
     // ---- head: avg-pool + max-pool, BatchNorm1d ----
-    if ((rc = launch_head_pool_fwd(st, x, net->N, net->head_hw, net->feat_dim, net->feat, net->head_arg))) return rc;
+    if ((rc = launch_head_pool_fwd(st, x, net->N, net->head_hw, net->feat_dim, net->feature_mode, net->feat, net->head_arg))) return rc;
     return launch_bn1d_fwd(st, net->feat, net->N, net->feat_dim, net->P + net->neck.g_off, net->P + net->neck.b_off, net->B + net->neck.rm_off,
                            net->B + net->neck.rv_off, tr ? 1 : 0, 0.1f, 1e-5f, emb, net->neck_mean, net->neck_invstd);
 }
@@ -486,7 +494,7 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
             if ((rc = launch_bn1d_bwd(st, net->feat, d_emb, net->N, net->feat_dim, net->P + net->neck.g_off, net->neck_mean, net->neck_invstd,
                                       net->dfeat, net->G + net->neck.g_off, net->G + net->neck.b_off))) return rc;
             net->cur_dy = net->gbuf[0];
-            if ((rc = launch_head_pool_bwd(st, net->dfeat, net->head_arg, net->N, net->head_hw, net->feat_dim, net->cur_dy))) return rc;
+            if ((rc = launch_head_pool_bwd(st, net->dfeat, net->head_arg, net->N, net->head_hw, net->feat_dim, net->feature_mode, net->cur_dy))) return rc;
             net->cur_dy_bytes = (int64_t)net->N * net->head_hw * net->feat_dim * 2;
         }
         for (int bi = net->stage_last[li]; bi >= net->stage_first[li]; --bi)

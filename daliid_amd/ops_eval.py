@@ -136,3 +136,22 @@ def class_targets(fvs, order, bounds, first_pick, num_proxies=5):
                                               _lib.ptr(first_pick, torch.int32, "first_pick"), int(num_proxies), _lib.ptr(centers),
                                               _lib.ptr(proxies), _lib.ptr(proxy_rows), _lib.ptr(max_dist)), "dali_class_targets")
     return centers, proxies, proxy_rows, max_dist
+
+
+def pairdist_blend(distmat, q, g, mags_prev=None, mags=None, precision="bf16x3", normalize=True):
+    """In place: distmat <- (w1*distmat + w2*(1 - q@g.T)) / (w1 + w2), w_m = max(qmag_m[:,None], gmag_m[None,:])
+    (evaluateCleanATModels.py:154-157), computed in the distance kernel's epilogue.  mags_prev = (q_mag, g_mag) of the
+    model that produced ``distmat``, mags = those of this model; both None -> plain average (:126)."""
+    assert q.dim() == 2 and g.dim() == 2 and q.shape[1] == g.shape[1] and tuple(distmat.shape) == (q.shape[0], g.shape[0])
+    assert (mags_prev is None) == (mags is None)
+    nq, ng, d = q.shape[0], g.shape[0], q.shape[1]
+    if nq == 0 or ng == 0:
+        return distmat
+    f32 = torch.float32
+    m = [None] * 4 if mags is None else [t.reshape(-1).contiguous().float() for t in (*mags_prev, *mags)]
+    if mags is not None:
+        assert m[0].numel() == nq and m[1].numel() == ng and m[2].numel() == nq and m[3].numel() == ng
+    _lib.check(_lib.lib().dali_pairdist_blend(_lib.ctx(q.device), _lib.stream_ptr(), _lib.ptr(q, f32, "q"), _lib.ptr(g, f32, "g"), nq, ng, d,
+                                               _PREC[precision], int(bool(normalize)), _lib.ptr(m[0]), _lib.ptr(m[1]), _lib.ptr(m[2]),
+                                               _lib.ptr(m[3]), _lib.ptr(distmat, f32, "distmat")), "dali_pairdist_blend")
+    return distmat

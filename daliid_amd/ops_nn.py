@@ -125,21 +125,24 @@ def maxpool_bn_bwd(dpool, arg, raw, mean, invstd, scale):
     return draw, dg, db
 
 
-def head_pool_fwd(x):
+FEATURE_MODES = {"both": 0, "gap": 1, "gmp": 2}        # dali_feature (evaluateCleanATModels.py:335-340)
+
+
+def head_pool_fwd(x, feature="both"):
     n, h, w, C = x.shape
     f = torch.empty(n, C, device=x.device, dtype=torch.float32)
     arg = torch.empty(n, C, device=x.device, dtype=torch.int16)
-    _lib.check(_lib.lib().dali_head_pool_fwd(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16), n, h * w, C, _lib.ptr(f), _lib.ptr(arg)),
-               "dali_head_pool_fwd")
+    _lib.check(_lib.lib().dali_head_pool_fwd(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16), n, h * w, C, FEATURE_MODES[feature],
+                                              _lib.ptr(f), _lib.ptr(arg)), "dali_head_pool_fwd")
     return f, arg
 
 
-def head_pool_bwd(df, arg, hw_shape):
+def head_pool_bwd(df, arg, hw_shape, feature="both"):
     n, C = df.shape
     h, w = hw_shape
     dx = torch.empty(n, h, w, C, device=df.device, dtype=bf16)
     _lib.check(_lib.lib().dali_head_pool_bwd(_lib.ctx(df.device), _lib.stream_ptr(), _lib.ptr(df, torch.float32), _lib.ptr(arg), n, h * w, C,
-                                              _lib.ptr(dx)), "dali_head_pool_bwd")
+                                              FEATURE_MODES[feature], _lib.ptr(dx)), "dali_head_pool_bwd")
     return dx
 
 

@@ -52,6 +52,9 @@ typedef enum { DALI_METRIC_COSINE = 0,   /* 1 - q.g         validateModels.py:47
 typedef enum { DALI_PREC_BF16X3 = 0,     /* split-bf16 (hi*hi+hi*lo+lo*hi), fp32 accumulate: ~1e-6 abs */
                DALI_PREC_BF16 = 1        /* single bf16 product, fp32 accumulate: ~1e-4 abs on unit rows */
 } dali_precision;
+/* pooling of the embedding head: the `feature` attribute eval scripts set through model.module
+ * (evaluateCleanATModels.py:249-256, :335-340); training always uses BOTH (Encoders.py:341-345). */
+typedef enum { DALI_FEATURE_BOTH = 0, DALI_FEATURE_GAP = 1, DALI_FEATURE_GMP = 2 } dali_feature;
 
 /* y = x / (|x|_2 + eps), rows of an fp32 [n,d] matrix.
  * validateModels.py:41-42 (eps = 0) and train_encodersKIT.py:198 (eps = 1e-9).
@@ -77,6 +80,16 @@ int dali_pairdist_prepare(dali_ctx* ctx, void* stream, const float* X, int n, in
 int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const uint16_t* q_hi, const uint16_t* q_lo,
                            const float* q_sq, const uint16_t* g_hi, const uint16_t* g_lo, const float* g_sq,
                            int nq, int ng, int d, int metric, float* out);
+
+/* Two-model distance fusion (evaluateCleanATModels.py:103-160): with inout holding the first model's distmat d1
+ * (dali_pairdist), computes the second model's d2 = 1 - q.g on the fly and stores
+ *   inout = (w1*d1 + w2*d2) / (w1 + w2),  w_m[q,g] = max(q_mag_m[q], g_mag_m[g])            (:154-157)
+ * where the magnitudes are the embedding norms under the chosen pooling (getWeightsByMagnitude :249-256);
+ * q_mag_prev/g_mag_prev belong to the first model, q_mag/g_mag to this one.  All four null: w = 1, i.e. the
+ * "simple ensemble" (d1 + d2)/2 (:126).  One extra read of the matrix instead of a second matrix + a blend pass. */
+int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
+                        int precision, int normalize, const float* q_mag_prev, const float* g_mag_prev,
+                        const float* q_mag, const float* g_mag, float* inout);
 
 /* market1501-protocol CMC / mAP: the arithmetic of torchreid.metrics.evaluate_rank(distmat, q_pids,
  * g_pids, q_camids, g_camids, use_metric_cuhk03=False) called at validateModels.py:68.
@@ -142,9 +155,11 @@ int dali_maxpool_bn_fwd(dali_ctx* ctx, void* stream, const uint16_t* raw, const 
 int dali_maxpool_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* dpool, const uint8_t* arg, const uint16_t* raw,
                         const float* mean, const float* invstd, const float* scale, int n, int h, int w, int C,
                         float* dgamma, float* dbeta, uint16_t* draw);
-/* Head (Encoders.py:341-345): f[n,c] = mean_hw x + max_hw x (fp32), and its backward. */
-int dali_head_pool_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, int n, int hw, int C, float* f, int16_t* arg);
-int dali_head_pool_bwd(dali_ctx* ctx, void* stream, const float* df, const int16_t* arg, int n, int hw, int C, uint16_t* dx);
+/* Head (Encoders.py:341-345): f[n,c] = mean_hw x + max_hw x (fp32), and its backward; mode = dali_feature
+ * (GAP: mean only, GMP: max only -- evaluateCleanATModels.py:335-340). */
+int dali_head_pool_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, int n, int hw, int C, int mode, float* f, int16_t* arg);
+int dali_head_pool_bwd(dali_ctx* ctx, void* stream, const float* df, const int16_t* arg, int n, int hw, int C, int mode,
+                       uint16_t* dx);
 /* BatchNorm1d neck (Encoders.py:350) on fp32 [n,C]. */
 int dali_bn1d_fwd(dali_ctx* ctx, void* stream, const float* x, int n, int C, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, int training, float momentum, float eps, float* y, float* mean,
@@ -264,6 +279,9 @@ int dali_resnet_stage_param_range(const dali_resnet* net, int stage, int64_t* be
 int dali_resnet_bind(dali_resnet* net, float* params, float* grads, float* buffers, void* arena, size_t arena_bytes);
 /* Rebuild the bf16 operand images from the fp32 master weights (call after every optimizer step / state load). */
 int dali_resnet_refresh_weights(dali_resnet* net, void* stream);
+/* Pooling of the embedding head for the next forward/backward calls (dali_feature; default BOTH).  Mirrors
+ * `model.module.feature = pooling` of evaluateCleanATModels.getWeightsByMagnitude (:249-256). */
+int dali_resnet_set_feature(dali_resnet* net, int mode);
 /* images fp32 NCHW -> emb fp32 [batch, feat_dim].  training != 0: batch statistics + running-stat update
  * (model.train()); else running statistics (model.eval()).  Stands under `model_online(batch_imgs)`
  * (train_encodersKIT.py:197) and `model(batch_gpu)` (getFeatures.py:61). */

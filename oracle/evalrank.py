@@ -38,6 +38,18 @@ def validate_features(q_fvs, g_fvs):
     return cosine_distmat(l2_normalize_rows(q_fvs), l2_normalize_rows(g_fvs))
 
 
+def fused_distmat(q1, g1, q2, g2, mags1=None, mags2=None):
+    """evaluateCleanATModels.py:114-126 and :154-157: d_m = 1 - unit(q_m) @ unit(g_m).T for the two models; with
+    magnitudes (norms of the embeddings under a pooling mode, :249-256) w_m[i,j] = max(qmag_m[i], gmag_m[j]) and
+    distmat = (w1*d1 + w2*d2)/(w1 + w2); without, the simple ensemble (d1 + d2)/2."""
+    d1, d2 = validate_features(q1, g1), validate_features(q2, g2)
+    if mags1 is None:
+        return (d1 + d2) / 2
+    w1 = torch.maximum(mags1[0].reshape(-1, 1).repeat(1, g1.shape[0]), mags1[1].reshape(1, -1).repeat(q1.shape[0], 1))
+    w2 = torch.maximum(mags2[0].reshape(-1, 1).repeat(1, g2.shape[0]), mags2[1].reshape(1, -1).repeat(q2.shape[0], 1))
+    return (w1 * d1 + w2 * d2) / (w1 + w2)
+
+
 def _codes(*arrays):
     """Map arbitrary (string) id arrays to shared int64 codes; equality is all that matters."""
     allv = np.concatenate([np.asarray(a).ravel() for a in arrays])

@@ -91,7 +91,13 @@ class ResNet50ReID(nn.Module):
         x = self.layer2(x)
         x = self.layer3(x)
         x = self.layer4(x)
-        x = self.global_avgpool(x) + self.global_maxpool(x)
+        feature = getattr(self, "feature", "both")            # evaluateCleanATModels.py:335-340 (eval-script variant)
+        if feature == "gap":
+            x = self.global_avgpool(x)
+        elif feature == "gmp":
+            x = self.global_maxpool(x)
+        else:
+            x = self.global_avgpool(x) + self.global_maxpool(x)
         x = x.view(x.size(0), -1)
         return self.last_bn(x)
 

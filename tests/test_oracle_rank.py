@@ -55,3 +55,16 @@ def test_l2sq_equals_2x_cosine_for_unit_rows():
     q = E.l2_normalize_rows(torch.randn(9, 33, generator=g))
     r = E.l2_normalize_rows(torch.randn(14, 33, generator=g))
     np.testing.assert_allclose(E.l2sq_distmat(q, r).numpy(), 2 * E.cosine_distmat(q, r).numpy(), atol=2e-6)
+
+
+def test_fused_distmat_known_answer():
+    """evaluateCleanATModels.py:154-157 by hand: one query, two gallery rows, two models."""
+    import torch
+    q1, g1 = torch.tensor([[2.0, 0.0]]), torch.tensor([[3.0, 0.0], [0.0, 5.0]])          # d1 = [0, 1]
+    q2, g2 = torch.tensor([[0.0, 1.0]]), torch.tensor([[1.0, 0.0], [0.0, 4.0]])          # d2 = [1, 0]
+    simple = E.fused_distmat(q1, g1, q2, g2)
+    assert torch.allclose(simple, torch.tensor([[0.5, 0.5]]))
+    m1 = (torch.tensor([[2.0]]), torch.tensor([[3.0], [5.0]]))                             # w1 = max(2,[3,5]) = [3,5]
+    m2 = (torch.tensor([[1.0]]), torch.tensor([[1.0], [4.0]]))                             # w2 = max(1,[1,4]) = [1,4]
+    fused = E.fused_distmat(q1, g1, q2, g2, m1, m2)
+    assert torch.allclose(fused, torch.tensor([[(3 * 0 + 1 * 1) / 4.0, (5 * 1 + 4 * 0) / 9.0]]))
