@@ -66,6 +66,9 @@ _SIGNATURES = {
     "dali_proxy_kmax": [],
     "dali_adam_step": [c_void_p] * 6 + [ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p],
     "dali_ema_update": [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_float],
+    "dali_triplet_loss_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p],
+    "dali_triplet_loss_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p],
     "dali_pairdist_blend": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
     "dali_class_targets": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -211,6 +211,67 @@ __global__ __launch_bounds__(256) void proxy_bwd_kernel(const int32_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// optional in-batch triplet head (BatchWeightedSoftmaxTripletLoss, losses.py:607-654), one wave64 per row.
+//   S = fn @ fn^T;  p_i = argmin_{j: y_j == y_i} S_ij (self included),  n_i = argmax_{j: y_j != y_i} S_ij
+//   row_i = -w_i log(e^{s_p/tau} / (e^{s_p/tau} + e^{s_n/tau})) = w_i softplus((s_n - s_p)/tau)
+//   rowstat[i] = {row_i, w_i};  sel_idx[i] = {p_i, n_i};  sel_coef[i] = d row_i / d s_n = -d row_i / d s_p
+// Ties go to the lowest index (torch.topk leaves them unspecified).  A row without any other-id sample has no
+// negative: the reference's topk raises there; the row is skipped and status[0] is set to 1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void triplet_rows_kernel(const float* __restrict__ S, const int32_t* __restrict__ y,
+                                                            const float* __restrict__ w, float inv_tau, int nb,
+                                                            float* __restrict__ rowstat, int32_t* __restrict__ sel_idx,
+                                                            float* __restrict__ sel_coef, int32_t* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nb) return;
+    const int yi = y[i];
+    const float* row = S + (size_t)i * nb;
+    float pmin = INFINITY, nmax = -INFINITY;
+    int pi = -1, ni = -1;
+    for (int j = lane; j < nb; j += 64) {
+        const float s = row[j];
+        if (y[j] == yi) { if (s < pmin) { pmin = s; pi = j; } }
+        else if (s > nmax) { nmax = s; ni = j; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float op = __shfl_xor(pmin, o); const int opi = __shfl_xor(pi, o);
+        const float on = __shfl_xor(nmax, o); const int oni = __shfl_xor(ni, o);
+        if (opi >= 0 && (pi < 0 || op < pmin || (op == pmin && opi < pi))) { pmin = op; pi = opi; }
+        if (oni >= 0 && (ni < 0 || on > nmax || (on == nmax && oni < ni))) { nmax = on; ni = oni; }
+    }
+    if (lane != 0) return;
+    if (ni < 0) {
+        rowstat[2 * i] = 0.f; rowstat[2 * i + 1] = 0.f;
+        sel_idx[2 * i] = -1; sel_idx[2 * i + 1] = -1; sel_coef[i] = 0.f;
+        status[0] = 1;
+        return;
+    }
+    const float x = (nmax - pmin) * inv_tau;
+    const float sp = x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));       // softplus
+    const float sg = 1.f / (1.f + expf(-x));
+    rowstat[2 * i] = w[i] * sp; rowstat[2 * i + 1] = w[i];
+    sel_idx[2 * i] = pi; sel_idx[2 * i + 1] = ni;
+    sel_coef[i] = w[i] * sg * inv_tau;
+}
+
+// dS_sym[i][j] = dS[i][j] + dS[j][i] with dS[i][n_i] = +c_i, dS[i][p_i] = -c_i, c_i = gscale/Z * sel_coef[i]
+// (the gradient wrt fn of a loss on S = fn fn^T is (dS + dS^T) fn).
+__global__ __launch_bounds__(256) void triplet_bwd_kernel(const int32_t* __restrict__ sel_idx, const float* __restrict__ sel_coef, int nb,
+                                                           const float* __restrict__ denom, float gscale, float* __restrict__ dS_sym) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)nb * nb) return;
+    const int i = (int)(t / nb), j = (int)(t % nb);
+    const float z = gscale / denom[0];
+    float v = 0.f;
+    if (sel_idx[2 * i + 1] == j) v += sel_coef[i];
+    if (sel_idx[2 * i] == j) v -= sel_coef[i];
+    if (sel_idx[2 * j + 1] == i) v += sel_coef[j];
+    if (sel_idx[2 * j] == i) v -= sel_coef[j];
+    dS_sym[t] = v * z;
+}
+
 }  // namespace dali
 
 using namespace dali;
@@ -261,3 +322,27 @@ extern "C" int dali_proxy_loss_bwd(dali_ctx* ctx, void* stream, const int32_t* s
 }
 
 extern "C" int dali_proxy_kmax(void) { return PROXY_KMAX; }
+
+extern "C" int dali_triplet_loss_fwd(dali_ctx* ctx, void* stream, const float* S, const int32_t* labels, const float* w, float tau, int nb,
+                                     float* rowstat, float* sums, int32_t* sel_idx, float* sel_coef, int32_t* status) {
+    DALI_REQUIRE(ctx && S && labels && w && rowstat && sums && sel_idx && sel_coef && status, "dali_triplet_loss_fwd: null argument");
+    DALI_REQUIRE(nb > 0 && tau > 0.f, "dali_triplet_loss_fwd: bad sizes nb=%d tau=%g", nb, tau);
+    hipStream_t st = (hipStream_t)stream;
+    DALI_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(triplet_rows_kernel, dim3((nb + 3) / 4), dim3(256), 0, st, S, labels, w, 1.0f / tau, nb, rowstat, sel_idx, sel_coef, status);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(1), dim3(256), 0, st, rowstat, nb, 2, sums);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+extern "C" int dali_triplet_loss_bwd(dali_ctx* ctx, void* stream, const int32_t* sel_idx, const float* sel_coef, int nb, const float* denom,
+                                     float gscale, float* dS_sym) {
+    DALI_REQUIRE(ctx && sel_idx && sel_coef && denom && dS_sym, "dali_triplet_loss_bwd: null argument");
+    DALI_REQUIRE(nb > 0 && nb <= 32768, "dali_triplet_loss_bwd: bad batch size %d", nb);
+    const size_t total = (size_t)nb * nb;
+    hipLaunchKernelGGL(triplet_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sel_idx, sel_coef, nb, denom,
+                       gscale, dS_sym);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}

@@ -8,6 +8,8 @@ Same names, argument order and return values as the reference:
       -> (loss, acc_bal, avg_max_prob)                                                     losses.py:39-88
   BatchWeightedProxyLoss(batch_fvs, batch_labels, samples_distortion, all_proxies, proxies_labels, current_epoch,
                          number_of_epoches, top_negs=50, tau=0.1, gpu_index=0) -> loss    losses.py:273-341
+  BatchWeightedSoftmaxTripletLoss(batch_fvs, batch_labels, samples_distortion, current_epoch, number_of_epoches,
+                                  tau=0.1, gpu_index=0) -> loss   (optional head)          losses.py:607-654
 ``loss`` is a differentiable 0-dim CUDA tensor (gradient wrt ``batch_fvs``).  ``LossHeads`` is the fused form the
 trainer mirror uses: both heads, one pass, no host synchronisation, data-parallel normalisers.
 """
@@ -163,6 +165,61 @@ def BatchWeightedProxyLoss(batch_fvs, batch_labels, samples_distortion, all_prox
     dev = batch_fvs.device
     w = _sample_weights(samples_distortion, current_epoch, number_of_epoches, dev)
     return _ProxyLossFn.apply(batch_fvs, all_proxies.contiguous(), _codes(batch_labels, dev), _codes(proxies_labels, dev), w, float(tau))
+
+
+def triplet_distortion_weights(current_epoch, number_of_epoches):
+    """losses.py:613-627: the 13-entry table of BatchWeightedSoftmaxTripletLoss."""
+    mins = (0.90, 0.85, 0.80, 0.75, 0.70, 0.6, 0.5, 0.4, 0.3, 0.2, 0.1, 0.1)
+    return torch.tensor([1.0] + [getValueFromCosineSchedule(current_epoch, number_of_epoches, n_min=m, n_max=1.0) for m in mins],
+                        dtype=torch.float32)
+
+
+def triplet_fwd(S, labels, w, tau):
+    nb, dev = S.shape[0], S.device
+    rowstat = torch.empty(nb, 2, device=dev, dtype=torch.float32)
+    sums = torch.empty(2, device=dev, dtype=torch.float32)
+    sel_idx = torch.empty(nb, 2, device=dev, dtype=torch.int32)
+    sel_coef = torch.empty(nb, device=dev, dtype=torch.float32)
+    status = torch.empty(1, device=dev, dtype=torch.int32)
+    _lib.check(_lib.lib().dali_triplet_loss_fwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(S, torch.float32, "S"), _lib.ptr(labels, torch.int32),
+                                                 _lib.ptr(w, torch.float32), float(tau), nb, _lib.ptr(rowstat), _lib.ptr(sums), _lib.ptr(sel_idx),
+                                                 _lib.ptr(sel_coef), _lib.ptr(status)), "dali_triplet_loss_fwd")
+    return rowstat, sums, sel_idx, sel_coef, status
+
+
+def triplet_bwd(sel_idx, sel_coef, denom, gscale=1.0):
+    nb = sel_idx.shape[0]
+    dS = torch.empty(nb, nb, device=sel_idx.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dali_triplet_loss_bwd(_lib.ctx(dS.device), _lib.stream_ptr(), _lib.ptr(sel_idx, torch.int32), _lib.ptr(sel_coef, torch.float32),
+                                                 nb, _lib.ptr(denom, torch.float32), float(gscale), _lib.ptr(dS)), "dali_triplet_loss_bwd")
+    return dS
+
+
+class _TripletLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fvs, labels, w, tau):
+        fvs = fvs.contiguous()
+        S = pairdist(fvs, fvs, metric="dot")
+        _, sums, sel_idx, sel_coef, status = triplet_fwd(S, labels, w, tau)
+        if int(status.item()) != 0:                # the reference's topk(k=1) on an empty negative set raises (losses.py:641)
+            raise _lib.DaliError("BatchWeightedSoftmaxTripletLoss: a sample has no negative in the batch (single identity)")
+        ctx.save_for_backward(fvs, sel_idx, sel_coef, sums)
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        fvs, sel_idx, sel_coef, sums = ctx.saved_tensors
+        dS = triplet_bwd(sel_idx, sel_coef, sums[1:2])
+        return pairdist(dS, fvs.t().contiguous(), metric="dot") * g, None, None, None        # (dS + dS^T) @ fvs
+
+
+def BatchWeightedSoftmaxTripletLoss(batch_fvs, batch_labels, samples_distortion, current_epoch, number_of_epoches, tau=0.1, gpu_index=0):
+    """losses.py:607-654 (optional head, not called by the trainer): in-batch hardest positive / hardest negative."""
+    dev = batch_fvs.device
+    table = triplet_distortion_weights(current_epoch, number_of_epoches).to(dev)
+    idx = samples_distortion if isinstance(samples_distortion, torch.Tensor) else torch.as_tensor(np.asarray(samples_distortion))
+    w = table[idx.to(dev).long()].contiguous()
+    return _TripletLossFn.apply(batch_fvs, _codes(batch_labels, dev), w, float(tau))
 
 
 class LossHeads:

@@ -233,6 +233,18 @@ int dali_adam_step(dali_ctx* ctx, void* stream, float* params, const float* grad
 /* momentum = beta*momentum + (1-beta)*online  (train_encodersKIT.py:218-226), flat. */
 int dali_ema_update(dali_ctx* ctx, void* stream, float* momentum, const float* online, int64_t n, float beta);
 
+/* ---- optional in-batch triplet head: BatchWeightedSoftmaxTripletLoss (losses.py:607-654) ------------------- *
+ * S [nb,nb] = fn @ fn^T (dali_pairdist, DOT); labels int32 codes; w [nb] = the 13-entry distortion table
+ * (losses.py:613-627) gathered per row.  Forward: rowstat [nb,2] = {w_i*softplus((s_neg - s_pos)/tau), w_i},
+ * sums[2] = {numerator, denominator} (loss = sums[0]/sums[1]), sel_idx [nb,2] = {hardest positive, hardest
+ * negative}, sel_coef [nb] = d row/d s_neg (= -d row/d s_pos); status[0] = 1 when some row has no negative (the
+ * reference's topk raises there; such rows are skipped).  Backward: dS_sym [nb,nb] = (dS + dS^T) * gscale/denom,
+ * so that d loss / d fn = dS_sym @ fn. */
+int dali_triplet_loss_fwd(dali_ctx* ctx, void* stream, const float* S, const int32_t* labels, const float* w, float tau, int nb,
+                          float* rowstat, float* sums, int32_t* sel_idx, float* sel_coef, int32_t* status);
+int dali_triplet_loss_bwd(dali_ctx* ctx, void* stream, const int32_t* sel_idx, const float* sel_coef, int nb, const float* denom,
+                          float gscale, float* dS_sym);
+
 /* ---- epoch targets: class centers + farthest-point proxies (train_encodersKIT.py:113-156, :252-284) -------- *
  * fvs [n,d] fp32 un-normalised embeddings.  order [n]: row indices sorted by identity; bounds [n_classes+1]:
  * identity c owns order[bounds[c] .. bounds[c+1]).  first_pick [n_classes]: position (0 .. n_c-1, within the

@@ -167,6 +167,36 @@ def gen_losses(ref_losses):
     print("schedule.npz ok")
 
 
+# --------------------------------------------------------------------------- optional triplet head
+def gen_triplet(ref_losses):
+    """BatchWeightedSoftmaxTripletLoss (losses.py:607-654): in-batch hardest positive / hardest negative per row,
+    13-entry distortion weight table."""
+    out, cases = {}, []
+    for name, nb, D, n_ids, epoch, n_epochs, tau, seed in (("pk_small", 32, 64, 8, 10, 250, 0.05, 300),
+                                                            ("pk_small_t0p1", 32, 64, 8, 1, 250, 0.1, 301),
+                                                            ("pk_256", 256, 256, 16, 120, 250, 0.05, 302),
+                                                            ("two_ids", 6, 32, 2, 250, 250, 0.1, 303)):
+        g = torch.Generator().manual_seed(seed)
+        ids = torch.randint(0, n_ids, (nb,), generator=g)
+        ids[0], ids[1] = 0, 1                                            # at least two identities
+        proto = unit_rows(n_ids, D, g)
+        fv = unit_rows(nb, D, g) + 0.8 * proto[ids]
+        fv = fv / fv.norm(dim=1, keepdim=True)
+        labels = (ids.numpy() * 5 + 2).astype(np.float32)
+        distortion = torch.randint(0, 13, (nb,), generator=g)
+        fn = fv.clone().requires_grad_(True)
+        loss = ref_losses.BatchWeightedSoftmaxTripletLoss(fn, torch.from_numpy(labels), distortion, epoch, n_epochs, tau=tau, gpu_index=0)
+        (grad,) = torch.autograd.grad(loss, fn)
+        pre = name + "/"
+        out[pre + "fv"], out[pre + "labels"], out[pre + "distortion"] = fv.numpy(), labels, distortion.numpy().astype(np.int64)
+        out[pre + "hyper"] = np.array([epoch, n_epochs, tau], dtype=np.float64)
+        out[pre + "loss"], out[pre + "grad"] = np.float32(loss.item()), grad.numpy()
+        cases.append(name)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "triplet.npz"), **out)
+    print("triplet.npz:", len(cases), "cases")
+
+
 # --------------------------------------------------------------------------- proxies
 def gen_proxies(T):
     out = {}
@@ -335,7 +365,11 @@ def gen_vit():
 def main():
     install_shims()
     import losses as ref_losses
+    if sys.argv[1:] == ["--only", "triplet"]:                            # added after the first fixtures were frozen
+        gen_triplet(ref_losses)
+        return
     gen_losses(ref_losses)
+    gen_triplet(ref_losses)
     import train_encodersKIT as T
     gen_proxies(T)
     gen_trainer(T)

@@ -102,3 +102,24 @@ def test_fused_adam_and_ema_match_torch():
         np.testing.assert_allclose(net.flat_params.cpu().numpy(), ref_p.detach().numpy(), rtol=2e-6, atol=1e-8)
         assert np.isclose(fused.weights_sqsum.item(), float(ref_p.detach().double().pow(2).sum()), rtol=1e-5)
     np.testing.assert_allclose(mom.flat_params.cpu().numpy(), mom_ref.numpy(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", [str(c) for c in load_golden("triplet.npz")["cases"]])
+def test_triplet_head_matches_reference_golden(L, name):
+    """Optional head BatchWeightedSoftmaxTripletLoss (losses.py:607-654) vs the reference's own outputs."""
+    z = load_golden("triplet.npz")
+    epoch, n_epochs, tau = z[name + "/hyper"]
+    fv = torch.from_numpy(z[name + "/fv"]).cuda().requires_grad_(True)
+    loss = L.BatchWeightedSoftmaxTripletLoss(fv, torch.from_numpy(z[name + "/labels"]), torch.from_numpy(z[name + "/distortion"]),
+                                             int(epoch), int(n_epochs), tau=tau, gpu_index=0)
+    loss.backward()
+    g_ref = z[name + "/grad"]
+    assert np.isclose(loss.item(), float(z[name + "/loss"]), rtol=2e-5, atol=2e-6)           # similarities by split-bf16 MFMA (~1e-6 abs)
+    np.testing.assert_allclose(fv.grad.cpu().numpy(), g_ref, rtol=2e-3, atol=2e-4 * float(np.abs(g_ref).max()))
+
+
+def test_triplet_head_single_identity_raises(L):
+    from daliid_amd._lib import DaliError
+    fv = torch.nn.functional.normalize(torch.randn(8, 32, device="cuda"))
+    with pytest.raises(DaliError):
+        L.BatchWeightedSoftmaxTripletLoss(fv, torch.ones(8), torch.zeros(8, dtype=torch.long), 1, 10)

@@ -45,3 +45,15 @@ def test_schedule_and_accbal():
         got = [O.cosine_schedule(int(a), int(b), n_min=m, n_max=1.0) for m in z["mins"]]
         np.testing.assert_allclose(got, row, rtol=0, atol=1e-15)
     assert np.isclose(O.acc_balanced(z["acc_pred"], z["acc_gt"]), z["acc_bal"], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", [str(c) for c in load_golden("triplet.npz")["cases"]])
+def test_triplet_head_matches_reference(name):
+    z = load_golden("triplet.npz")
+    epoch, n_epochs, tau = z[name + "/hyper"]
+    fv = torch.from_numpy(z[name + "/fv"]).requires_grad_(True)
+    loss = O.softmax_triplet_loss(fv, torch.from_numpy(z[name + "/labels"]), torch.from_numpy(z[name + "/distortion"]),
+                                  int(epoch), int(n_epochs), tau)
+    (g,) = torch.autograd.grad(loss, fv)
+    assert np.isclose(loss.item(), float(z[name + "/loss"]), rtol=3e-6, atol=1e-6)
+    np.testing.assert_allclose(g.numpy(), z[name + "/grad"], rtol=1e-4, atol=2e-6 * float(np.abs(z[name + "/grad"]).max()) + 1e-9)
