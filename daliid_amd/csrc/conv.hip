@@ -34,6 +34,14 @@ __device__ __forceinline__ void decode_pixel(const GatherGeom& g, int p, int& n,
     }
 }
 
+// element index of output pixel p (GEMM N index) in the [pixels][Cm] output tensor
+__device__ __forceinline__ size_t out_pixel(const GatherGeom& g, int p) {
+    if (!g.sub) return (size_t)p;
+    int n, ho, wo;
+    decode_pixel(g, p, n, ho, wo);
+    return ((size_t)n * g.Hfull + (2 * ho + g.oph)) * g.Wfull + (2 * wo + g.opw);
+}
+
 // offset (elements) of tap (r,s) for base coords, or -1 if the tap falls outside / is not hit
 __device__ __forceinline__ long long tap_offset(const GatherGeom& g, long long img_base, int h0, int w0, int r, int s) {
     int hi, wi;
@@ -143,12 +151,13 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
         const int p = tn * TN + nb + j * 16;
+        const size_t opix = (p < a.P) ? out_pixel(a.g, p) : 0;
 #pragma unroll
         for (int i = 0; i < Cfg::FM; ++i) {
             const int c = tm * TM + mb + i * 16;
             if (p < a.P && c < a.Cm) {      // Cm is a multiple of 4: the 4 channels are all valid
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                const size_t o = (size_t)p * a.Cm + c;
+                const size_t o = opix * a.Cm + c;
                 if (a.bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
@@ -277,8 +286,8 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const GatherGeom g = a.g;
-    const int K = g.R * g.S * g.Ck;
-    const int ktiles = K >> 5;
+    const int K = g.R * g.S * g.Ck;                    // weight row length
+    const int ktiles = (g.nr * g.ns * g.Ck) >> 5;      // taps actually visited (all of them unless g.sub)
 
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
     const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
         int n = 0, ho = 0, wo = 0;
         const bool ok = p < a.P;
         if (ok) decode_pixel(g, p, n, ho, wo);
+        if (g.sub) { ho = 2 * ho + g.oph; wo = 2 * wo + g.opw; }
         if (g.mode == 0) { b_h0[i] = ho * g.stride - g.pad; b_w0[i] = wo * g.stride - g.pad; }
         else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
         if (!ok) b_h0[i] = -0x40000000;                             // never in range
@@ -309,7 +319,8 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     }
 
     // wave-uniform k position
-    int kr = 0, ks = 0, kc0 = 0;
+    int kr = g.r0, ks = g.s0, kc0 = 0;
+    const int ks_end = g.s0 + g.sstep * g.ns;
     auto issue = [&](int stage) {
         uint16_t* sa = smem + stage * Cfg::STAGE_ELEMS;
         uint16_t* sb = sa + Cfg::A_ELEMS;
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
         }
         // advance (channel block fastest, then s, then r)
         kc0 += 32;
-        if (kc0 == g.Ck) { kc0 = 0; if (++ks == g.S) { ks = 0; ++kr; } }
+        if (kc0 == g.Ck) { kc0 = 0; ks += g.sstep; if (ks >= ks_end) { ks = g.s0; kr += g.rstep; } }
     };
 
     f32x4_t acc[FM][FN];
@@ -401,8 +412,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const GatherGeom g = a.g;
-    const int K = g.R * g.S * g.Ck;
-    const int ktiles = K >> 5;
+    const int K = g.R * g.S * g.Ck;                    // weight row length
+    const int ktiles = (g.nr * g.ns * g.Ck) >> 5;      // taps actually visited (all of them unless g.sub)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
     const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
@@ -421,12 +432,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
         int n = 0, ho = 0, wo = 0;
         const bool ok = p < a.P;
         if (ok) decode_pixel(g, p, n, ho, wo);
+        if (g.sub) { ho = 2 * ho + g.oph; wo = 2 * wo + g.opw; }
         if (g.mode == 0) { b_h0[i] = ho * g.stride - g.pad; b_w0[i] = wo * g.stride - g.pad; }
         else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
         if (!ok) b_h0[i] = -0x40000000;
         b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;
     }
-    int kr = 0, ks = 0, kc0 = 0;
+    int kr = g.r0, ks = g.s0, kc0 = 0;
+    const int ks_end = g.s0 + g.sstep * g.ns;
     auto issue = [&](int stage) {
         uint16_t* sa = smem + stage * STAGE_ELEMS;
         uint16_t* sb = sa + A_ELEMS;
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + NW * i) * 512), 16, off, 0, 0, 0);
         }
         kc0 += 32;
-        if (kc0 == g.Ck) { kc0 = 0; if (++ks == g.S) { ks = 0; ++kr; } }
+        if (kc0 == g.Ck) { kc0 = 0; ks += g.sstep; if (ks >= ks_end) { ks = g.s0; kr += g.rstep; } }
     };
     f32x4_t acc[4][4];
 #pragma unroll
@@ -973,7 +986,49 @@ struct ProfScope {
 };
 
 // Host-side launchers shared with the net plan (resnet_plan.hip).
+static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a);
+
+// Stride-2 data gradients are split by output parity: output position (2h'+ph, 2w'+pw) only receives the taps
+// kr = (ph+pad) mod 2 + 2i, ks likewise, so each of the four classes is a dense stride-1-like problem on a quarter of
+// the pixels with 1, 2, 2 and 4 of a 3x3 kernel's 9 taps (the un-split form multiplies 3/4 zero operands).  A class
+// without taps (1x1 kernels: three of four) contributes nothing; it is skipped when the residual is accumulated in
+// place (Res == O), otherwise the un-split path is used.
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
+    IGemmArgs args = a;
+    GatherGeom& g = args.g;
+    g.sub = 0; g.oph = g.opw = 0; g.Hfull = g.Hout; g.Wfull = g.Wout;
+    g.r0 = 0; g.rstep = 1; g.nr = g.R; g.s0 = 0; g.sstep = 1; g.ns = g.S;
+    static const bool no_split = getenv("DALI_DGRAD_NOSPLIT") != nullptr;
+    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const bool dma_ok = !a.in_scale && x_bytes < 0x7ff00000ll && (long long)a.Cm * g.R * g.S * g.Ck * 2 < 0x7ff00000ll;
+    if (g.mode == 1 && g.stride == 2 && dma_ok && !a.stats && !no_split && (g.Hout % 2) == 0 && (g.Wout % 2) == 0 &&
+        ilog2_exact(g.Wout / 2) >= 0 && ilog2_exact((g.Hout / 2) * (g.Wout / 2)) >= 0) {
+        int nr[2], ns[2];
+        for (int ph = 0; ph < 2; ++ph) {
+            const int r0 = (ph + g.pad) & 1, s0 = (ph + g.pad) & 1;
+            nr[ph] = r0 < g.R ? (g.R - r0 + 1) / 2 : 0;
+            ns[ph] = s0 < g.S ? (g.S - s0 + 1) / 2 : 0;
+        }
+        const bool all_have = nr[0] && nr[1] && ns[0] && ns[1];
+        if (all_have || (a.Res != nullptr && a.Res == a.O)) {
+            for (int ph = 0; ph < 2; ++ph)
+                for (int pw = 0; pw < 2; ++pw) {
+                    if (nr[ph] * ns[pw] == 0) continue;
+                    IGemmArgs s = args;
+                    s.g.sub = 1; s.g.oph = ph; s.g.opw = pw; s.g.Hfull = g.Hout; s.g.Wfull = g.Wout;
+                    s.g.Hout = g.Hout / 2; s.g.Wout = g.Wout / 2; s.P = a.P / 4;
+                    s.g.r0 = (ph + g.pad) & 1; s.g.rstep = 2; s.g.nr = nr[ph];
+                    s.g.s0 = (pw + g.pad) & 1; s.g.sstep = 2; s.g.ns = ns[pw];
+                    const int rc = launch_igemm_conv_one(st, s);
+                    if (rc) return rc;
+                }
+            return DALI_OK;
+        }
+    }
+    return launch_igemm_conv_one(st, args);
+}
+
+static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const bool in_bn = a.in_scale != nullptr;
     const bool narrow = a.Cm <= 64;
     IGemmArgs args = a;
@@ -982,7 +1037,7 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     // the LDS-DMA kernel addresses both tensors with 32-bit byte offsets through buffer descriptors
     const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
     const bool dma_ok = !in_bn && x_bytes < 0x7ff00000ll && (long long)a.Cm * a.g.R * a.g.S * a.g.Ck * 2 < 0x7ff00000ll;
-    const int K = a.g.R * a.g.S * a.g.Ck;
+    const int K = a.g.nr * a.g.ns * a.g.Ck;               // reduction length actually visited
     const int cfg = conv_pick_cfg(a.Cm, a.P, K);
     if (!dma_ok && !in_bn && a.stats && (cfg == CONV_128x256 || cfg == CONV_256x256)) {
         set_error("conv: tensors beyond 2 GiB are not supported together with the BatchNorm statistics epilogue");

@@ -13,6 +13,11 @@ struct GatherGeom {
     long long img_pitch;       // elements between images of the gathered tensor
     int row_pitch, pix_pitch;  // elements between rows / pixels
     int lw, lhw;               // log2(Wout), log2(Hout*Wout) or -1
+    // stride-2 dgrad by output parity (set by launch_igemm_conv; LDS-DMA kernels only): the GEMM enumerates the sub-grid
+    // (n, ho', wo') of output positions (2ho'+oph, 2wo'+opw) of a Hfull x Wfull tensor; only the taps whose parity
+    // matches contribute: kr = r0, r0+2, ... (nr of them), ks = s0, s0+2, ... (ns).  sub == 0: r0 = s0 = 0, all taps.
+    int sub, oph, opw, Hfull, Wfull;
+    int r0, rstep, nr, s0, sstep, ns;
 };
 
 struct IGemmArgs {

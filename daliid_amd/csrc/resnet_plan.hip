@@ -468,9 +468,10 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     uint16_t* dx = d_a2;                                          // d_a2 is dead now
     if (b.has_ds) {
         if ((rc = conv_wgrad(net, st, b.cd, b.x, nullptr, d_rawd))) return rc;
-        uint16_t* tmp = next_gbuf(net, dz, d_a1, d_rawd, dx);
-        if ((rc = conv_dgrad(net, st, b.cd, d_rawd, nullptr, tmp))) return rc;
-        if ((rc = conv_dgrad(net, st, b.c1, d_a1, tmp, dx))) return rc;
+        // conv1's data gradient first, then the downsample branch accumulates into it in place: with stride 2 only the
+        // even-even quarter of the positions receives a contribution (launch_igemm_conv's parity split)
+        if ((rc = conv_dgrad(net, st, b.c1, d_a1, nullptr, dx))) return rc;
+        if ((rc = conv_dgrad(net, st, b.cd, d_rawd, dx, dx))) return rc;
     } else {
         if ((rc = conv_dgrad(net, st, b.c1, d_a1, dz, dx))) return rc;
     }

@@ -29,13 +29,16 @@ def conv2d_fwd(x, w, stride=1, pad=0, in_scale=None, in_shift=None, in_relu=Fals
     return (y, stats) if want_stats else y
 
 
-def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, residual=None):
-    """dy [N,Ho,Wo,Cout] bf16, wt [Cin,R,S,Cout] bf16 -> dx [N,H,W,Cin] bf16 (+ residual)."""
+def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, residual=None, inplace=False):
+    """dy [N,Ho,Wo,Cout] bf16, wt [Cin,R,S,Cout] bf16 -> dx [N,H,W,Cin] bf16 (+ residual).  ``inplace``: accumulate into
+    ``residual`` itself (residual == dx; what the net plan does for the downsample branch)."""
     n, ho, wo, cout = dy.shape
     cin, r, s, _ = wt.shape
     h, wd = x_hw
     assert _out_hw(h, wd, r, s, stride, pad) == (ho, wo)
-    dx = torch.empty(n, h, wd, cin, device=dy.device, dtype=bf16)
+    if inplace:
+        assert residual is not None and tuple(residual.shape) == (n, h, wd, cin) and residual.is_contiguous()
+    dx = residual if inplace else torch.empty(n, h, wd, cin, device=dy.device, dtype=bf16)
     _lib.check(_lib.lib().dali_conv2d_dgrad(_lib.ctx(dy.device), _lib.stream_ptr(), _lib.ptr(dy, bf16, "dy"), _lib.ptr(wt, bf16, "wt"),
                                              _lib.ptr(dx), _lib.ptr(residual), n, h, wd, cin, cout, r, s, stride, pad),
                "dali_conv2d_dgrad")

@@ -21,6 +21,9 @@ CASES = [
     (2, 8, 8, 64, 96, 3, 3, 2, 1),        # 3x3 stride 2
     (5, 7, 3, 96, 160, 3, 3, 1, 1),       # ragged everything
     (4, 16, 8, 512, 512, 3, 3, 1, 1),     # layer4 conv2 shape (small batch)
+    (2, 32, 16, 128, 128, 3, 3, 2, 1),    # layer2 conv2 (stride 2): dgrad split by output parity, 4 sub-problems
+    (3, 6, 10, 32, 64, 3, 3, 2, 1),       # stride 2 on a grid whose halves are not powers of two: un-split dgrad
+    (2, 16, 8, 256, 512, 1, 1, 2, 0),     # layer2 downsample: in-place dgrad touches the even-even quarter only
 ]
 
 
@@ -71,6 +74,9 @@ def test_conv_fwd_dgrad_wgrad_exact_integers(nn, case):
         res = _ints((n, h, w, cin), gen)
         dxr = nn.conv2d_dgrad(dyg, w_dg, (h, w), stride, pad, residual=res.to(bf16).cuda())
         assert torch.equal(dxr.cpu(), (ref_dx + res).to(bf16))
+        buf = res.to(bf16).cuda()                                            # accumulate in place (residual == dx)
+        dxi = nn.conv2d_dgrad(dyg, w_dg, (h, w), stride, pad, residual=buf, inplace=True)
+        assert dxi.data_ptr() == buf.data_ptr() and torch.equal(dxi.cpu(), (ref_dx + res).to(bf16))
     # weight gradient (fp32, exact)
     dwk = nn.conv2d_wgrad(xg, dyg, (r, s), stride, pad)
     ref_dw = wt.grad.permute(0, 2, 3, 1).contiguous()
