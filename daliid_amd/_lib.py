@@ -40,8 +40,8 @@ _SIGNATURES = {
     "dali_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_int],
     "dali_bn_finalize": [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
-    "dali_bn_act": [c_void_p] * 9 + [c_int, ctypes.c_int64, c_int, c_void_p],
-    "dali_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_int64, c_int] + [c_void_p] * 16,
+    "dali_bn_act": [c_void_p] * 9 + [c_int, ctypes.c_int64, c_int, c_void_p, c_void_p],
+    "dali_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_int64, c_int] + [c_void_p] * 16,
     "dali_maxpool_bn_fwd": [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p],
     "dali_maxpool_bn_bwd": [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p],
     "dali_head_pool_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

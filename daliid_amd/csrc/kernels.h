@@ -71,10 +71,10 @@ int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, d
 int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                           float* scale, float* shift);
 int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,
-                  const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y);
+                  const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y, uint8_t* mask_out);
 int bn_bwd_blocks(int P, int C, int* rows_per_block);
 size_t bn_bwd_partial_floats(int P, int C, bool dual);
-int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
+int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const uint8_t* ybits, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
                   float* partial, float* coef_a, float* coef_b, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
                   uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out, double* scratch);
 int launch_stem_pack_image(hipStream_t st, const float* img, int N, int H, int W, uint16_t* out);

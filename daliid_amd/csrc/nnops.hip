@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint16_t* __restrict_
                                                       const float* __restrict__ shift, const uint16_t* __restrict__ idn,
                                                       const uint16_t* __restrict__ raw2, const float* __restrict__ scale2,
                                                       const float* __restrict__ shift2, int relu, size_t chunks, int C,
-                                                      uint16_t* __restrict__ y) {
+                                                      uint16_t* __restrict__ y, uint8_t* __restrict__ mask_out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
         const int c = (int)((i * 8) % (size_t)C);
         float v[8], sc[8], sh[8];
@@ -116,6 +116,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint16_t* __restrict_
             for (int t = 0; t < 8; ++t) v[t] = fmaxf(v[t], 0.f);
         }
         *reinterpret_cast<uint4*>(y + i * 8) = pack8(v);
+        if (mask_out) {                              // bit t = (y[c+t] > 0): what the backward needs of y, at 1/16 of its bytes
+            unsigned m = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) m |= (v[t] > 0.f ? 1u : 0u) << t;
+            mask_out[i] = (uint8_t)m;
+        }
     }
 }
 
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint16_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 template <bool DUAL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ymask,
-                                                             BnBwdSide a, BnBwdSide b, int relu, int P, int C,
+                                                             const uint8_t* __restrict__ ybits, BnBwdSide a, BnBwdSide b, int relu, int P, int C,
                                                              int rows_per_block, float* __restrict__ partial) {
     extern __shared__ float red[];                  // [rows_in_flight][C][NV]
     constexpr int NV = DUAL ? 3 : 2;                // S1, S2a, (S2b)
@@ -145,14 +151,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
     if (rsub < rif) {
         float ma[8], ia[8], sa[8], ha[8], mb[8], ib[8];
         load8f(a.mean + c, ma); load8f(a.invstd + c, ia);
-        if (!ymask && relu) { load8f(a.scale + c, sa); load8f(a.shift + c, ha); }
+        if (!ymask && !ybits && relu) { load8f(a.scale + c, sa); load8f(a.shift + c, ha); }
         if (DUAL) { load8f(b.mean + c, mb); load8f(b.invstd + c, ib); }
         for (int p = p0 + rsub; p < p1; p += rif) {
             const size_t o = (size_t)p * C + c;
             float gv[8], rv[8];
             unpack8(*reinterpret_cast<const uint4*>(g + o), gv);
             unpack8(*reinterpret_cast<const uint4*>(a.raw + o), rv);
-            if (ymask) {
+            if (ybits) {
+                const unsigned m = ybits[o >> 3];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) gv[t] = ((m >> t) & 1u) ? gv[t] : 0.f;
+            } else if (ymask) {
                 float yv[8];
                 unpack8(*reinterpret_cast<const uint4*>(ymask + o), yv);
 #pragma unroll
@@ -185,19 +195,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
     }
 }
 
-// partial [blocks][C][NV] -> coef [C][3] = (scale, S1/N, S2/N), dgamma = S2, dbeta = S1 (accumulate optional)
+// partial [blocks][C][NV] -> dgamma = S2, dbeta = S1 and the folded apply coefficients, structure-of-arrays coef [3][C]:
+//   draw = scale*(dz - S1/N - xhat*S2/N),  xhat = (raw - mean)*invstd
+//        = A*dz + K - Q*raw   with  A = scale,  Q = scale*invstd*S2/N,  K = Q*mean - scale*S1/N
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int blocks, int C, int NV,
                                                                int which, double count, const float* __restrict__ scale,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                float* __restrict__ coef, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, const float* __restrict__ invstd_unused) {
+                                                               float* __restrict__ dbeta) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
         double a = 0.0, b = 0.0;
 #pragma unroll 8
         for (int t = 0; t < blocks; ++t) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
-        coef[c * 3 + 0] = scale[c];
-        coef[c * 3 + 1] = (float)(a / count);
-        coef[c * 3 + 2] = (float)(b / count);
+        const double sc = (double)scale[c];
+        const double q = sc * (double)invstd[c] * (b / count);
+        coef[c] = scale[c];
+        coef[C + c] = (float)(q * (double)mean[c] - sc * (a / count));
+        coef[2 * C + c] = (float)q;
         dgamma[c] = (float)b;
         dbeta[c] = (float)a;
     }
@@ -205,17 +220,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 
 template <bool DUAL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ymask,
-                                                            BnBwdSide a, BnBwdSide b, const float* __restrict__ coef_a,
-                                                            const float* __restrict__ coef_b, int relu, size_t chunks, int C,
-                                                            uint16_t* __restrict__ draw_a, uint16_t* __restrict__ draw_b,
-                                                            uint16_t* __restrict__ dz_out) {
+                                                            const uint8_t* __restrict__ ybits, BnBwdSide a, BnBwdSide b,
+                                                            const float* __restrict__ coef_a, const float* __restrict__ coef_b, int relu,
+                                                            size_t chunks, int C, uint16_t* __restrict__ draw_a,
+                                                            uint16_t* __restrict__ draw_b, uint16_t* __restrict__ dz_out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
         const int c = (int)((i * 8) % (size_t)C);
-        float gv[8], rv[8], ma[8], ia[8];
+        float gv[8], rv[8];
         unpack8(*reinterpret_cast<const uint4*>(g + i * 8), gv);
         unpack8(*reinterpret_cast<const uint4*>(a.raw + i * 8), rv);
-        load8f(a.mean + c, ma); load8f(a.invstd + c, ia);
-        if (ymask) {
+        if (ybits) {
+            const unsigned m = ybits[i];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gv[t] = ((m >> t) & 1u) ? gv[t] : 0.f;
+        } else if (ymask) {
             float yv[8];
             unpack8(*reinterpret_cast<const uint4*>(ymask + i * 8), yv);
 #pragma unroll
@@ -226,21 +244,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
 #pragma unroll
             for (int t = 0; t < 8; ++t) gv[t] = (rv[t] * sa[t] + ha[t]) > 0.f ? gv[t] : 0.f;
         }
-        float o[8];
+        float A[8], K[8], Q[8], o[8];
+        load8f(coef_a + c, A); load8f(coef_a + C + c, K); load8f(coef_a + 2 * C + c, Q);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float* cf = coef_a + (c + t) * 3;
-            o[t] = cf[0] * (gv[t] - cf[1] - ((rv[t] - ma[t]) * ia[t]) * cf[2]);
-        }
+        for (int t = 0; t < 8; ++t) o[t] = A[t] * gv[t] + K[t] - Q[t] * rv[t];
         if (DUAL) {
-            float r2[8], mb[8], ib[8], o2[8];
+            float r2[8], o2[8];
             unpack8(*reinterpret_cast<const uint4*>(b.raw + i * 8), r2);
-            load8f(b.mean + c, mb); load8f(b.invstd + c, ib);
+            load8f(coef_b + c, A); load8f(coef_b + C + c, K); load8f(coef_b + 2 * C + c, Q);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float* cf = coef_b + (c + t) * 3;
-                o2[t] = cf[0] * (gv[t] - cf[1] - ((r2[t] - mb[t]) * ib[t]) * cf[2]);
-            }
+            for (int t = 0; t < 8; ++t) o2[t] = A[t] * gv[t] + K[t] - Q[t] * r2[t];
             *reinterpret_cast<uint4*>(draw_b + i * 8) = pack8(o2);
         }
         if (dz_out) *reinterpret_cast<uint4*>(dz_out + i * 8) = pack8(gv);     // may alias g (same index, read first)
@@ -395,15 +408,12 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const uint16_
         const int cc = (int)(i % cpr) * 8;
         const size_t p = i / cpr;
         const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
-        float dz[8], rv[8], m[8], iv[8], o[8];
+        float dz[8], rv[8], A[8], K[8], Q[8], o[8];
         maxpool_gather_dz(dp, arg, n, h, w, cc, C, Ho, Wo, dz);
         unpack8(*reinterpret_cast<const uint4*>(raw + p * C + cc), rv);
-        load8f(mean + cc, m); load8f(invstd + cc, iv);
+        load8f(coef + cc, A); load8f(coef + C + cc, K); load8f(coef + 2 * C + cc, Q);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float* cf = coef + (cc + t) * 3;
-            o[t] = cf[0] * (dz[t] - cf[1] - ((rv[t] - m[t]) * iv[t]) * cf[2]);
-        }
+        for (int t = 0; t < 8; ++t) o[t] = A[t] * dz[t] + K[t] - Q[t] * rv[t];
         *reinterpret_cast<uint4*>(draw + p * C + cc) = pack8(o);
     }
 }
@@ -572,9 +582,9 @@ int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta,
     return DALI_OK;
 }
 int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,
-                  const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y) {
+                  const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y, uint8_t* mask_out) {
     const size_t chunks = elems / 8;
-    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(chunks)), dim3(256), 0, st, raw, scale, shift, idn, raw2, scale2, shift2, relu, chunks, C, y);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(chunks)), dim3(256), 0, st, raw, scale, shift, idn, raw2, scale2, shift2, relu, chunks, C, y, mask_out);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -590,7 +600,7 @@ int bn_bwd_blocks(int P, int C, int* rows_per_block) {
     *rows_per_block = rpb;
     return blocks;
 }
-int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
+int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, const uint8_t* ybits, const BnBwdSide& a, const BnBwdSide* b, int relu, int P, int C,
                   float* partial, float* coef_a, float* coef_b, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
                   uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out, double* scratch) {
     int rpb;
@@ -601,24 +611,24 @@ int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, cons
     const size_t lds = (size_t)rif * C * NV * sizeof(float);
     BnBwdSide bb = dual ? *b : a;
     if (dual) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), lds, st, g, ymask, a, bb, relu, P, C, rpb, partial);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), lds, st, g, ymask, ybits, a, bb, relu, P, C, rpb, partial);
     } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), lds, st, g, ymask, a, bb, relu, P, C, rpb, partial);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), lds, st, g, ymask, ybits, a, bb, relu, P, C, rpb, partial);
     }
     DALI_LAUNCH_CHECK();
     int S, rc;
     if ((rc = reduce_partials(st, partial, blocks, C * NV, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 1, (double)P, a.scale, coef_a,
-                       dgamma_a, dbeta_a, (const float*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 1, (double)P, a.scale, a.mean, a.invstd,
+                       coef_a, dgamma_a, dbeta_a);
     DALI_LAUNCH_CHECK();
     if (dual) {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 2, (double)P, bb.scale, coef_b,
-                           dgamma_b, dbeta_b, (const float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 2, (double)P, bb.scale, bb.mean, bb.invstd,
+                           coef_b, dgamma_b, dbeta_b);
         DALI_LAUNCH_CHECK();
     }
     const size_t chunks = (size_t)P * C / 8;
-    if (dual) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, a, bb, coef_a, coef_b, relu, chunks, C, draw_a, draw_b, dz_out);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, a, bb, coef_a, coef_a, relu, chunks, C, draw_a, draw_b, dz_out);
+    if (dual) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, ybits, a, bb, coef_a, coef_b, relu, chunks, C, draw_a, draw_b, dz_out);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, ybits, a, bb, coef_a, coef_a, relu, chunks, C, draw_a, draw_b, dz_out);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -663,8 +673,8 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     DALI_LAUNCH_CHECK();
     int S, rc;
     if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 1, (double)P, scale, coef, dgamma,
-                       dbeta, (const float*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 1, (double)P, scale, mean, invstd, coef,
+                       dgamma, dbeta);
     DALI_LAUNCH_CHECK();
     hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 8))), dim3(256), 0, st, dp, arg, raw, mean, invstd, coef, N, H,
                        W, C, Ho, Wo, draw);
@@ -723,23 +733,24 @@ extern "C" int dali_bn_finalize(dali_ctx* ctx, void* stream, const float* partia
 
 extern "C" int dali_bn_act(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift,
                            const uint16_t* identity, const uint16_t* raw2, const float* scale2, const float* shift2, int relu,
-                           int64_t pixels, int C, uint16_t* y) {
+                           int64_t pixels, int C, uint16_t* y, uint8_t* mask_out) {
     DALI_REQUIRE(ctx && raw && scale && shift && y, "dali_bn_act: null argument");
     DALI_REQUIRE(C % 8 == 0 && pixels >= 0, "dali_bn_act: C must be a multiple of 8");
     DALI_REQUIRE(!(identity && raw2), "dali_bn_act: identity and raw2 are exclusive");
     DALI_REQUIRE(!raw2 || (scale2 && shift2), "dali_bn_act: raw2 needs scale2/shift2");
     if (pixels == 0) return DALI_OK;
-    return launch_bn_act((hipStream_t)stream, raw, scale, shift, identity, raw2, scale2, shift2, relu, (size_t)pixels * C, C, y);
+    return launch_bn_act((hipStream_t)stream, raw, scale, shift, identity, raw2, scale2, shift2, relu, (size_t)pixels * C, C, y, mask_out);
 }
 
-extern "C" int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* ymask, int relu, int64_t pixels, int C,
+extern "C" int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* ymask, const uint8_t* ybits, int relu, int64_t pixels, int C,
                            const uint16_t* raw_a, const float* mean_a, const float* invstd_a, const float* scale_a, const float* shift_a,
                            const uint16_t* raw_b, const float* mean_b, const float* invstd_b, const float* scale_b,
                            float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, uint16_t* draw_a, uint16_t* draw_b,
                            uint16_t* dz_out) {
     DALI_REQUIRE(ctx && g && raw_a && mean_a && invstd_a && scale_a && dgamma_a && dbeta_a && draw_a, "dali_bn_bwd: null argument");
     DALI_REQUIRE(C % 8 == 0 && C <= 2048 && pixels > 0 && pixels < (1ll << 31), "dali_bn_bwd: C must be a multiple of 8, <= 2048");
-    DALI_REQUIRE(ymask || !relu || shift_a, "dali_bn_bwd: relu mask needs ymask or scale/shift");
+    DALI_REQUIRE(ymask || ybits || !relu || shift_a, "dali_bn_bwd: relu mask needs ymask, ybits or scale/shift");
+    DALI_REQUIRE(!(ymask && ybits), "dali_bn_bwd: ymask and ybits are exclusive");
     const bool dual = raw_b != nullptr;
     DALI_REQUIRE(!dual || (mean_b && invstd_b && scale_b && dgamma_b && dbeta_b && draw_b), "dali_bn_bwd: incomplete second side");
     const size_t pf = bn_bwd_partial_floats((int)pixels, C, dual);
@@ -752,7 +763,7 @@ extern "C" int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const
     double* scratch = reinterpret_cast<double*>(ws + align_up(pf * 4, 256) + 2 * align_up((size_t)C * 12, 256));
     BnBwdSide a{raw_a, mean_a, invstd_a, scale_a, shift_a};
     BnBwdSide b{raw_b, mean_b, invstd_b, scale_b, nullptr};
-    return launch_bn_bwd((hipStream_t)stream, g, ymask, a, dual ? &b : nullptr, relu, (int)pixels, C, partial, coef_a, coef_b, dgamma_a, dbeta_a,
+    return launch_bn_bwd((hipStream_t)stream, g, ymask, ybits, a, dual ? &b : nullptr, relu, (int)pixels, C, partial, coef_a, coef_b, dgamma_a, dbeta_a,
                          dgamma_b, dbeta_b, draw_a, draw_b, dz_out, scratch);
 }
 

@@ -38,6 +38,7 @@ struct Block {
     Bn b1, b2, b3, bd;
     bool has_ds;
     int hin, win, hout, wout, cin, width, cout;
+    uint8_t* ybits = nullptr;                                  // ReLU mask of y, one bit per element (dali_bn_act mask_out)
     uint16_t *x, *raw1, *a1, *raw2, *a2, *raw3, *rawd, *y;    // a = relu(bn(raw)), materialised once (fused
 };                                                              // apply-on-load repeats the VALU work per tap and per M-tile)
 
@@ -221,6 +222,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
         reserve(net, a, b.a2, pout * b.width * 2);
         reserve(net, a, b.raw3, pout * b.cout * 2);
         reserve(net, a, b.y, pout * b.cout * 2);
+        reserve(net, a, b.ybits, pout * b.cout / 8);
         if (b.has_ds) reserve(net, a, b.rawd, pout * b.cout * 2);
         reserve_bn(net, a, b.b1); reserve_bn(net, a, b.b2); reserve_bn(net, a, b.b3);
         if (b.has_ds) reserve_bn(net, a, b.bd);
@@ -413,16 +415,16 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
         b.x = const_cast<uint16_t*>(x);
         const size_t e1 = (size_t)net->N * b.hin * b.win * b.width, e2 = (size_t)net->N * b.hout * b.wout * b.width;
         if ((rc = conv_bn_fwd(net, st, b.c1, b.b1, x, nullptr, b.raw1, tr))) return rc;
-        if ((rc = launch_bn_act(st, b.raw1, b.b1.scale, b.b1.shift, nullptr, nullptr, nullptr, nullptr, 1, e1, b.width, b.a1))) return rc;
+        if ((rc = launch_bn_act(st, b.raw1, b.b1.scale, b.b1.shift, nullptr, nullptr, nullptr, nullptr, 1, e1, b.width, b.a1, nullptr))) return rc;
         if ((rc = conv_bn_fwd(net, st, b.c2, b.b2, b.a1, nullptr, b.raw2, tr))) return rc;
-        if ((rc = launch_bn_act(st, b.raw2, b.b2.scale, b.b2.shift, nullptr, nullptr, nullptr, nullptr, 1, e2, b.width, b.a2))) return rc;
+        if ((rc = launch_bn_act(st, b.raw2, b.b2.scale, b.b2.shift, nullptr, nullptr, nullptr, nullptr, 1, e2, b.width, b.a2, nullptr))) return rc;
         if ((rc = conv_bn_fwd(net, st, b.c3, b.b3, b.a2, nullptr, b.raw3, tr))) return rc;
         const size_t elems = (size_t)net->N * b.hout * b.wout * b.cout;
         if (b.has_ds) {
             if ((rc = conv_bn_fwd(net, st, b.cd, b.bd, x, nullptr, b.rawd, tr))) return rc;
-            rc = launch_bn_act(st, b.raw3, b.b3.scale, b.b3.shift, nullptr, b.rawd, b.bd.scale, b.bd.shift, 1, elems, b.cout, b.y);
+            rc = launch_bn_act(st, b.raw3, b.b3.scale, b.b3.shift, nullptr, b.rawd, b.bd.scale, b.bd.shift, 1, elems, b.cout, b.y, tr ? b.ybits : nullptr);
         } else {
-            rc = launch_bn_act(st, b.raw3, b.b3.scale, b.b3.shift, x, nullptr, nullptr, nullptr, 1, elems, b.cout, b.y);
+            rc = launch_bn_act(st, b.raw3, b.b3.scale, b.b3.shift, x, nullptr, nullptr, nullptr, 1, elems, b.cout, b.y, tr ? b.ybits : nullptr);
         }
         if (rc) return rc;
         x = b.y;
@@ -442,7 +444,7 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     BnBwdSide s3{b.raw3, b.b3.mean, b.b3.invstd, b.b3.scale, b.b3.shift};
     BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
     // y = relu(bn3(raw3) + identity): dz = dy*(y>0) written in place over dy
-    rc = launch_bn_bwd(st, dy, b.y, s3, b.has_ds ? &sd : nullptr, 1, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
+    rc = launch_bn_bwd(st, dy, nullptr, b.ybits, s3, b.has_ds ? &sd : nullptr, 1, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
                        net->G + b.b3.g_off, net->G + b.b3.b_off, b.has_ds ? net->G + b.bd.g_off : nullptr, b.has_ds ? net->G + b.bd.b_off : nullptr,
                        d_raw3, d_rawd, dy, net->red_scratch);
     if (rc) return rc;
@@ -454,14 +456,14 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     // bn2 + relu, in place.  The ReLU mask is recomputed from raw2 (raw*scale+shift > 0 <=> a2 > 0: bf16 rounding cannot
     // flush a positive fp32 to zero) instead of reading a2: one tensor read less in each of the two passes.
     BnBwdSide s2{b.raw2, b.b2.mean, b.b2.invstd, b.b2.scale, b.b2.shift};
-    if ((rc = launch_bn_bwd(st, d_a2, nullptr, s2, nullptr, 1, Pout, b.width, net->bwd_partial, b.b2.coef, nullptr, net->G + b.b2.g_off,
+    if ((rc = launch_bn_bwd(st, d_a2, nullptr, nullptr, s2, nullptr, 1, Pout, b.width, net->bwd_partial, b.b2.coef, nullptr, net->G + b.b2.g_off,
                             net->G + b.b2.b_off, nullptr, nullptr, d_a2, nullptr, nullptr, net->red_scratch))) return rc;
     // conv2
     if ((rc = conv_wgrad(net, st, b.c2, b.a1, nullptr, d_a2))) return rc;
     uint16_t* d_a1 = d_raw3;                                      // d_raw3 is dead now
     if ((rc = conv_dgrad(net, st, b.c2, d_a2, nullptr, d_a1))) return rc;
     BnBwdSide s1{b.raw1, b.b1.mean, b.b1.invstd, b.b1.scale, b.b1.shift};
-    if ((rc = launch_bn_bwd(st, d_a1, nullptr, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
+    if ((rc = launch_bn_bwd(st, d_a1, nullptr, nullptr, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
                             net->G + b.b1.b_off, nullptr, nullptr, d_a1, nullptr, nullptr, net->red_scratch))) return rc;
     // conv1 (+ identity / downsample branch)
     if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;

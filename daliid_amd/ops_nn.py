@@ -75,16 +75,18 @@ def bn_finalize(partial, count, gamma, beta, running_mean=None, running_var=None
     return scale, shift, mean, invstd
 
 
-def bn_act(raw, scale, shift, identity=None, raw2=None, scale2=None, shift2=None, relu=True):
+def bn_act(raw, scale, shift, identity=None, raw2=None, scale2=None, shift2=None, relu=True, want_mask=False):
+    """-> y, or (y, mask bytes [numel/8]: bit t of byte i = y.flatten()[8i+t] > 0) with ``want_mask``."""
     C = raw.shape[-1]
     y = torch.empty_like(raw)
+    mask = torch.empty(raw.numel() // 8, device=raw.device, dtype=torch.uint8) if want_mask else None
     _lib.check(_lib.lib().dali_bn_act(_lib.ctx(raw.device), _lib.stream_ptr(), _lib.ptr(raw, bf16), _lib.ptr(scale), _lib.ptr(shift),
                                        _lib.ptr(identity), _lib.ptr(raw2), _lib.ptr(scale2), _lib.ptr(shift2), int(relu),
-                                       raw.numel() // C, C, _lib.ptr(y)), "dali_bn_act")
-    return y
+                                       raw.numel() // C, C, _lib.ptr(y), _lib.ptr(mask)), "dali_bn_act")
+    return (y, mask) if want_mask else y
 
 
-def bn_bwd(g, raw_a, mean_a, invstd_a, scale_a, shift_a=None, ymask=None, relu=True, side_b=None, want_dz=False):
+def bn_bwd(g, raw_a, mean_a, invstd_a, scale_a, shift_a=None, ymask=None, relu=True, side_b=None, want_dz=False, ybits=None):
     """-> (draw_a, dgamma_a, dbeta_a[, draw_b, dgamma_b, dbeta_b][, dz])"""
     C = g.shape[-1]
     dev = g.device
@@ -96,7 +98,7 @@ def bn_bwd(g, raw_a, mean_a, invstd_a, scale_a, shift_a=None, ymask=None, relu=T
         rb, mb, ib, sb = side_b
         draw_b, dgb, dbb = torch.empty_like(g), _f32(C, dev), _f32(C, dev)
     dz = torch.empty_like(g) if want_dz else None
-    _lib.check(_lib.lib().dali_bn_bwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(g, bf16), _lib.ptr(ymask), int(relu), pixels, C,
+    _lib.check(_lib.lib().dali_bn_bwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(g, bf16), _lib.ptr(ymask), _lib.ptr(ybits), int(relu), pixels, C,
                                        _lib.ptr(raw_a, bf16), _lib.ptr(mean_a), _lib.ptr(invstd_a), _lib.ptr(scale_a), _lib.ptr(shift_a),
                                        _lib.ptr(rb), _lib.ptr(mb), _lib.ptr(ib), _lib.ptr(sb), _lib.ptr(dga), _lib.ptr(dba),
                                        _lib.ptr(dgb), _lib.ptr(dbb), _lib.ptr(draw_a), _lib.ptr(draw_b), _lib.ptr(dz)), "dali_bn_bwd")

@@ -136,15 +136,18 @@ int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x, const uint
 int dali_bn_finalize(dali_ctx* ctx, void* stream, const float* partial, int tiles, int C, double count,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, float* scale, float* shift, float* mean, float* invstd);
-/* y = relu?(raw*scale+shift + identity) with identity = identity tensor | raw2*scale2+shift2 | nothing (bottleneck tail). */
+/* y = relu?(raw*scale+shift + identity) with identity = identity tensor | raw2*scale2+shift2 | nothing (bottleneck tail).
+ * mask_out (nullable, [pixels*C/8] bytes): bit t of byte i = (y[8i+t] > 0), the ReLU mask the backward needs, at 1/16 of
+ * y's bytes. */
 int dali_bn_act(dali_ctx* ctx, void* stream, const uint16_t* raw, const float* scale, const float* shift,
                 const uint16_t* identity, const uint16_t* raw2, const float* scale2, const float* shift2, int relu,
-                int64_t pixels, int C, uint16_t* y);
-/* Backward of z = bn(raw) followed by an optional ReLU whose mask is (ymask > 0) if ymask is given, else
- * (raw*scale+shift > 0).  g = gradient after the ReLU.  Writes d(raw) (bf16), dgamma, dbeta; with a second side
+                int64_t pixels, int C, uint16_t* y, uint8_t* mask_out);
+/* Backward of z = bn(raw) followed by an optional ReLU whose mask is the bit mask ybits (dali_bn_act's mask_out) or
+ * (ymask > 0) if one of them is given (they are exclusive), else (raw*scale+shift > 0).  g = gradient after the ReLU.  Writes d(raw) (bf16), dgamma, dbeta; with a second side
  * (raw_b...) the same masked gradient also flows through a second BatchNorm (the downsample branch).  dz_out
  * (nullable, may alias g) receives the masked gradient.  draw_a may alias g when dz_out is null. */
-int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* ymask, int relu, int64_t pixels, int C,
+int dali_bn_bwd(dali_ctx* ctx, void* stream, const uint16_t* g, const uint16_t* ymask, const uint8_t* ybits, int relu,
+                int64_t pixels, int C,
                 const uint16_t* raw_a, const float* mean_a, const float* invstd_a, const float* scale_a, const float* shift_a,
                 const uint16_t* raw_b, const float* mean_b, const float* invstd_b, const float* scale_b,
                 float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, uint16_t* draw_a, uint16_t* draw_b,

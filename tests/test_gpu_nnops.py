@@ -54,6 +54,11 @@ def test_bn_stats_finalize_act(nn, shape):
     close_bf16(nn.bn_act(raw, scale, shift, raw2=idn.cuda(), scale2=scale, shift2=shift, relu=True),
                F.relu(rawf * sc + sh + idn.float() * sc + sh))
     close_bf16(nn.bn_act(raw, scale, shift, relu=False), rawf * sc + sh)
+    # the 1-bit ReLU mask written beside y (what the backward reads instead of y)
+    yk, bits = nn.bn_act(raw, scale, shift, identity=idn.cuda(), relu=True, want_mask=True)
+    expect = (yk.flatten().float() > 0).view(-1, 8).to(torch.int32)
+    expect = (expect << torch.arange(8, device=expect.device, dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, expect)
 
 
 def _bn_ref(raw, gamma, beta, eps=1e-5):
@@ -99,6 +104,13 @@ def test_bn_bwd_inner_and_block_output(nn, shape):
     close_bf16(draw_b, rb.grad, ulps=1.5, atol=2e-3 * float(rb.grad.abs().max()))
     for got, ref in ((dga, gm.grad), (dba, bt.grad), (dgb, gmb.grad), (dbb, btb.grad)):
         np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    # same thing with the mask bits instead of the y tensor: identical results
+    bits = (y16.flatten().float() > 0).view(-1, 8).to(torch.int32)
+    bits = (bits << torch.arange(8, dtype=torch.int32)).sum(1).to(torch.uint8).cuda()
+    out2 = nn.bn_bwd(grad.cuda(), raw.cuda(), mean.cuda(), invstd.cuda(), scale.cuda(), shift.cuda(), ybits=bits, relu=True,
+                     side_b=(raw_b.cuda(), mean_b.cuda(), invstd_b.cuda(), scale_b.cuda()), want_dz=True)
+    for t1, t2 in zip(out, out2):
+        assert torch.equal(t1, t2)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 6, 64), (3, 16, 8, 32), (1, 6, 10, 64)])
