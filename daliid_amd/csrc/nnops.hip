@@ -30,16 +30,19 @@ __device__ __forceinline__ void load8f(const float* __restrict__ p, float (&f)[8
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, int rows, int cols, int S, double* __restrict__ out) {
     const int col = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
     if (col >= cols) return;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // 4 independent chains keep 4+ loads in flight
+    double acc[8];                                      // 8 independent chains keep 8 loads in flight (latency-bound pass)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
     int r = s;
-    for (; r + 3 * S < rows; r += 4 * S) {
-        a0 += (double)in[(size_t)r * cols + col];
-        a1 += (double)in[(size_t)(r + S) * cols + col];
-        a2 += (double)in[(size_t)(r + 2 * S) * cols + col];
-        a3 += (double)in[(size_t)(r + 3 * S) * cols + col];
+    for (; r + 7 * S < rows; r += 8 * S) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = in[(size_t)(r + u * S) * cols + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += (double)v[u];
     }
-    for (; r < rows; r += S) a0 += (double)in[(size_t)r * cols + col];
-    out[(size_t)s * cols + col] = (a0 + a1) + (a2 + a3);
+    for (; r < rows; r += S) acc[0] += (double)in[(size_t)r * cols + col];
+    out[(size_t)s * cols + col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int tiles, int C, double count,
@@ -556,9 +559,9 @@ static inline int grid_for(size_t work_items, int cap = 16384) {
 // ---- host launchers (shared with the net plan) ----------------------------------------------------
 // two-level: `rows` partial rows of `cols` floats -> S fp64 rows in scratch (S <= REDUCE_SMAX)
 int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out) {
-    int S = rows / 16;                          // >= 16 rows per first-level thread; second level loops S <= 16
+    int S = rows / 8;                           // >= 8 rows (one round of 8 loads) per first-level thread
     if (S < 1) S = 1;
-    if (S > 16) S = 16;
+    if (S > REDUCE_SMAX) S = REDUCE_SMAX;       // the second level (finalize kernels) loops over S rows
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256, S), dim3(256), 0, st, partial, rows, cols, S, scratch);
     DALI_LAUNCH_CHECK();
     *S_out = S;
