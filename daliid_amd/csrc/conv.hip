@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     int tm, tn;
     if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const GatherGeom g = a.g;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     if (AHEAD == 2 && ktiles > 1) issue(1);
     if (AHEAD == 2 && ktiles > 1) dma_wait<NDMA>(); else dma_wait<0>();
     __builtin_amdgcn_s_barrier();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     int st_cur = 0, st_nxt2 = AHEAD;
     for (int kt = 0; kt < ktiles; ++kt) {
         if (kt + AHEAD < ktiles) issue(st_nxt2);
@@ -390,8 +392,13 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
         st_nxt2 = (st_nxt2 == NSTAGE - 1) ? 0 : st_nxt2 + 1;
     }
     __syncthreads();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 
     conv_epilogue<Cfg>(a, acc, tm, tn, smem);
+    if (a.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have been acknowledged
+        if (tid == 0) a.stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // Wave-grid variant for the large layers: WM x WN waves, each owning a 64 x 64 sub-tile (same per-wave code and register
@@ -987,6 +994,7 @@ struct ProfScope {
 
 // Host-side launchers shared with the net plan (resnet_plan.hip).
 static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a);
+static unsigned long long* g_conv_stamps = nullptr;      // diagnostic only, see dali_debug_set_conv_stamps
 
 // Stride-2 data gradients are split by output parity: output position (2h'+ph, 2w'+pw) only receives the taps
 // kr = (ph+pad) mod 2 + 2i, ks likewise, so each of the four classes is a dense stride-1-like problem on a quarter of
@@ -995,6 +1003,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a);
 // place (Res == O), otherwise the un-split path is used.
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     IGemmArgs args = a;
+    args.stamps = g_conv_stamps;
     GatherGeom& g = args.g;
     g.sub = 0; g.oph = g.opw = 0; g.Hfull = g.Hout; g.Wfull = g.Wout;
     g.r0 = 0; g.rstep = 1; g.nr = g.R; g.s0 = 0; g.sstep = 1; g.ns = g.S;
@@ -1136,6 +1145,10 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
 }
 
 }  // namespace dali
+
+// Diagnostic (not in include/daliid.h): device buffer of 4 x uint64 per block that the LDS-DMA conv kernel fills with
+// s_memrealtime stamps (100 MHz); null switches it off.  scripts/conv_block_timeline.py reads it.
+extern "C" int dali_debug_set_conv_stamps(void* dev_ptr) { g_conv_stamps = static_cast<unsigned long long*>(dev_ptr); return DALI_OK; }
 
 extern "C" int dali_gemm_profile_begin(dali_ctx* ctx, int max_launches) {
     DALI_REQUIRE(ctx && max_launches > 0, "dali_gemm_profile_begin: bad argument");

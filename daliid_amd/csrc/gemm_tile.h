@@ -130,24 +130,42 @@ __device__ __forceinline__ void acc_coords(int& m_base, int& n_base) {
     n_base = (wave & 1) * (Cfg::TN / 2) + (lane & 15);
 }
 
-// XCD-aware block -> tile map.  Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the XCD
-// group); each group walks 8x8 "super-tiles" so the 64 blocks resident on one XCD share 8 A panels and
-// 8 B panels through that XCD's L2, and the 8 XCDs work on super-tiles of the same A super-row (shared
-// through the Infinity Cache).  Returns false for padding blocks.  Speed only, never correctness.
+// XCD-aware block -> tile map.  Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the XCD group); each group
+// walks 64-tile "super-tiles" of SM x SN tiles so the 64 blocks resident on one XCD share SM A panels and SN B panels
+// through that XCD's L2, and the 8 XCDs work on neighbouring super-tiles (shared through the Infinity Cache).
+// A super-tile holds 2^lg <= 64 tiles (fewer when the problem has < 1024 tiles, so that all 8 XCDs get work);
+// SM = min(8, next power of two >= tiles_m), SN = 2^lg / SM: with fewer than 8 tile rows (most convolutions: Cm < 1024)
+// a fixed 8 x 8 super-tile would be 50-88 % padding blocks, each of which still costs a workgroup launch and its LDS
+// allocation.  Inside a super-tile m runs fastest: the M-tiles of one pixel tile run back to back (the pixel panel is
+// fetched from HBM once, and one pixel's output row is completed while its DRAM page is open).
+// Returns false for padding blocks.  Speed only, never correctness.
+__host__ __device__ __forceinline__ void xcd_super_shape(int tiles_m, int tiles_n, int& lg, int& ms) {
+    // super-tile = 2^lg tiles, at most 64 and small enough that every XCD gets at least two of them
+    const long long total = (long long)tiles_m * tiles_n;
+    lg = total >= 1024 ? 6 : total >= 512 ? 5 : total >= 256 ? 4 : 3;
+    ms = tiles_m >= 5 ? 3 : tiles_m >= 3 ? 2 : tiles_m == 2 ? 1 : 0;
+    if (ms > lg) ms = lg;
+}
 __device__ __forceinline__ bool xcd_tile_map(int b, int tiles_m, int tiles_n, int& tm, int& tn) {
+    int lg, ms;
+    xcd_super_shape(tiles_m, tiles_n, lg, ms);
+    const int ns = lg - ms;
     const int xcd = b & 7, slot = b >> 3;
-    const int ssn = (tiles_n + 7) >> 3;
-    const int st = (slot >> 6) * 8 + xcd;          // super-tile index
-    const int w = slot & 63;
+    const int ssn = (tiles_n + (1 << ns) - 1) >> ns;
+    const int st = (slot >> lg) * 8 + xcd;          // super-tile index
+    const int w = slot & ((1 << lg) - 1);
     const int sm = st / ssn, sn = st - sm * ssn;
-    tm = sm * 8 + (w >> 3);
-    tn = sn * 8 + (w & 7);
+    tm = (sm << ms) + (w & ((1 << ms) - 1));
+    tn = (sn << ns) + (w >> ms);
     return tm < tiles_m && tn < tiles_n;
 }
 inline int xcd_tile_grid(int tiles_m, int tiles_n) {
-    const int ssm = (tiles_m + 7) / 8, ssn = (tiles_n + 7) / 8;
+    int lg, ms;
+    xcd_super_shape(tiles_m, tiles_n, lg, ms);
+    const int ns = lg - ms;
+    const int ssm = (tiles_m + (1 << ms) - 1) >> ms, ssn = (tiles_n + (1 << ns) - 1) >> ns;
     const int st = ssm * ssn;
-    return ((st + 7) / 8) * 8 * 64;
+    return (((st + 7) / 8) * 8) << lg;
 }
 
 }  // namespace dali
