@@ -138,16 +138,132 @@ struct WeightLoader {
     }
 };
 
-// Shared epilogue: bf16 store of O (+ residual) and the per-tile BatchNorm partial statistics.
+// workgroup barrier that orders LDS traffic only (no wait for outstanding global loads / stores)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+// same, after also waiting for this wave's global loads (data loaded into registers and then written to LDS)
+__device__ __forceinline__ void lds_barrier_vm() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row (rotate-and-add: 4 VALU ops, no LDS crossbar)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+// Shared epilogue: the per-tile BatchNorm partial statistics and the bf16 store of O (+ residual).
+// In-kernel stamps on the short-K layers showed the epilogue, not the memory system, bounding the kernel: 8 us of a 10 us
+// workgroup lifetime in VALU / LDS-crossbar work (statistics by 128 ds_bpermute shuffles, per-element predicates and
+// 64-bit address arithmetic, 8-byte stores scattered over 16 cache lines per instruction) while the stores themselves
+// drained in 0.2 us.  Hence: statistics first, reduced with DPP row rotates; barriers that order LDS traffic only (a
+// __syncthreads() would wait for the global stores); and for interior tiles of the plain convolution a lean path that
+// stages the tile through LDS as [pixel][TM channels] bf16 and writes 16 bytes per lane, TM/8 adjacent lanes covering
+// one pixel's contiguous TM*2 bytes, without per-element predicates.  Values and rounding are identical on every path.
 template <int FM_, int FN_> struct EpiShape { static constexpr int FM = FM_, FN = FN_; };
 // Generic over the block shape: TM x TN tile, WNW waves along n, NT threads; this wave sits at (wm, wn) and owns an
 // (FM*16) x (FN*16) sub-tile.
 template <int TM, int TN, int FM_, int FN_, int WNW, int NT>
 __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&acc)[FM_][FN_], int tm, int tn, uint16_t* smem, int wm, int wn) {
     using Cfg = EpiShape<FM_, FN_>;
+    static_assert(FN_ % 2 == 0, "the staged store splits the tile's pixels in two halves");
     const int lane = threadIdx.x & 63;
     const int mb = wm * (FM_ * 16) + (lane >> 4) * 4, nb = wn * (FN_ * 16) + (lane & 15);
-    // ---- store O (+ residual) ----
+    // ---- BatchNorm partial statistics: per channel sum / sumsq over this tile's pixels ----
+    if (a.stats) {
+        lds_barrier();                             // mainloop LDS reads are done: reuse smem
+        float* red = reinterpret_cast<float*>(smem);   // [WNW (wn)][TM][2]
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i) {
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < Cfg::FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s1[r] += v; s2[r] += v * v; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+            if ((lane & 15) == 0) {
+                const int ml = mb + i * 16;              // first of this lane's 4 channels inside the tile
+                float4* d = reinterpret_cast<float4*>(red + (wn * TM + ml) * 2);
+                d[0] = make_float4(s1[0], s2[0], s1[1], s2[1]);
+                d[1] = make_float4(s1[2], s2[2], s1[3], s2[3]);
+            }
+        }
+        lds_barrier();
+        for (int t = threadIdx.x; t < TM; t += NT) {
+            const int c = tm * TM + t;
+            if (c < a.Cm) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WNW; ++w) { const float2 v = *reinterpret_cast<const float2*>(red + (w * TM + t) * 2); s1 += v.x; s2 += v.y; }
+                *reinterpret_cast<float2*>(a.stats + ((size_t)tn * a.Cm + c) * 2) = make_float2(s1, s2);
+            }
+        }
+        lds_barrier();                             // the partial sums have been read: smem is free for the staged store
+    }
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 5] = __builtin_amdgcn_s_memrealtime();     // stats done
+
+    // ---- lean path: plain convolution (optionally + residual), interior tile, natural output addressing ----
+    const bool plain = !a.bias && !a.O2 && a.act == 0 && !a.dact_pre && !a.g.sub && (a.Cm & 7) == 0;
+    const bool interior = (tm + 1) * TM <= a.Cm && (tn + 1) * TN <= a.P;
+    if (plain && interior) {
+        constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
+        constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
+        static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
+        char* stage = reinterpret_cast<char*>(smem);
+        char* my_stage = stage + (wn * WROWS + (lane & 15)) * ROWB + mb * 2;              // + jj*16*ROWB + i*32
+        const int ch = threadIdx.x % CPR, lp0 = threadIdx.x / CPR;                        // read-out: 16-byte chunk / first row
+        if (!a.stats) lds_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
+            if (a.Res) {                                        // residual tile -> LDS with 16-byte loads, same layout as the output
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lp = lp0 + it * (NT / CPR);
+                    const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
+                    *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) =
+                        *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + gbase + (size_t)q * a.Cm * 2);
+                }
+                lds_barrier_vm();                               // the loaded residual is visible to every wave
+            }
+#pragma unroll
+            for (int jj = 0; jj < HFN; ++jj) {
+                const int j = h * HFN + jj;
+#pragma unroll
+                for (int i = 0; i < Cfg::FM; ++i) {
+                    float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                    uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
+                    if (a.Res) {
+                        const uint2 rv = *slot;
+                        v0 += bf16_bits_to_f32(rv.x & 0xffffu); v1 += bf16_bits_to_f32(rv.x >> 16);
+                        v2 += bf16_bits_to_f32(rv.y & 0xffffu); v3 += bf16_bits_to_f32(rv.y >> 16);
+                    }
+                    *slot = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+            }
+            lds_barrier();
+            if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 6 + 2 * h] = __builtin_amdgcn_s_memrealtime();   // half staged
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int lp = lp0 + it * (NT / CPR);
+                const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);                  // pixel inside the tile, minus h*WROWS
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O) + gbase + (size_t)q * a.Cm * 2) =
+                    *reinterpret_cast<const uint4*>(stage + lp * ROWB + ch * 16);
+            }
+            if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 7 + 2 * h] = __builtin_amdgcn_s_memrealtime();   // half's stores issued
+            if (h == 0) lds_barrier();                          // the LDS reads are done before the second half overwrites them
+        }
+        return;
+    }
+
+    // ---- general path: edge tiles, linear-layer epilogues (bias / GELU / GELU' / second output), parity sub-problems ----
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
         const int p = tn * TN + nb + j * 16;
@@ -181,43 +297,6 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
                 }
                 *reinterpret_cast<uint2*>(a.O + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
-        }
-    }
-    // ---- BatchNorm partial statistics: per channel sum / sumsq over this tile's pixels ----
-    if (a.stats) {
-        __syncthreads();                           // mainloop LDS reads are done: reuse smem
-        float* red = reinterpret_cast<float*>(smem);   // [WNW (wn)][TM][2]
-#pragma unroll
-        for (int i = 0; i < Cfg::FM; ++i) {
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < Cfg::FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s1[r] += v; s2[r] += v * v; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
-            }
-            if ((lane & 15) == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ml = mb + i * 16 + r;          // channel inside the tile
-                    red[(wn * TM + ml) * 2 + 0] = s1[r];
-                    red[(wn * TM + ml) * 2 + 1] = s2[r];
-                }
-            }
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < TM; t += NT) {
-            const int c = tm * TM + t;
-            if (c < a.Cm) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WNW; ++w) { s1 += red[(w * TM + t) * 2]; s2 += red[(w * TM + t) * 2 + 1]; }
-                float* dst = a.stats + ((size_t)tn * a.Cm + c) * 2;
-                dst[0] = s1; dst[1] = s2;
             }
         }
     }
@@ -275,7 +354,8 @@ __device__ __forceinline__ void dma_wait() {
 }
 
 template <int TM, int TN, int NSTAGE>
-__global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+    // 128 x 128: <= 128 VGPRs (4 waves per SIMD); the 64 x 256 shape carries twice the per-lane gather state and would spill
     using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
     constexpr int FM = Cfg::FM, FN = Cfg::FN;
     constexpr int A_BLK = TM / 16 / 4, B_BLK = TN / 16 / 4;      // 1 KiB DMA blocks (16 rows x 64 B) per wave per k-tile
@@ -283,7 +363,7 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     int tm, tn;
     if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const GatherGeom g = a.g;
@@ -371,7 +451,7 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
     if (AHEAD == 2 && ktiles > 1) issue(1);
     if (AHEAD == 2 && ktiles > 1) dma_wait<NDMA>(); else dma_wait<0>();
     __builtin_amdgcn_s_barrier();
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
     int st_cur = 0, st_nxt2 = AHEAD;
     for (int kt = 0; kt < ktiles; ++kt) {
         if (kt + AHEAD < ktiles) issue(st_nxt2);
@@ -392,12 +472,16 @@ __global__ __launch_bounds__(256) void igemm_conv_dma_kernel(IGemmArgs a, int ti
         st_nxt2 = (st_nxt2 == NSTAGE - 1) ? 0 : st_nxt2 + 1;
     }
     __syncthreads();
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
 
     conv_epilogue<Cfg>(a, acc, tm, tn, smem);
     if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();   // all stores issued (not yet acknowledged)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have been acknowledged
-        if (tid == 0) a.stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime();
+            a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued;
+        }
     }
 }
 
@@ -945,7 +1029,7 @@ namespace dali {
 // Tile configuration per problem (measured on MI355X, scripts/bench_convs.py): 64x256 for <= 64 output channels;
 // 256x256 / 16 waves / 4-deep ring when both K and Cm are large (operand traffic per FLOP halves: +25..36 % on the
 // layer4 3x3); 128x256 / 8 waves for Cm = 256 with K >= 1024; 128x128 / 4 waves otherwise (small K: prologue-bound).
-enum ConvCfg { CONV_NARROW = 0, CONV_128 = 1, CONV_128x256 = 2, CONV_256x256 = 3 };
+enum ConvCfg { CONV_NARROW = 0, CONV_128 = 1, CONV_128x256 = 2, CONV_256x256 = 3, CONV_256x128 = 4 };
 static int conv_cfg_override() {
     static int v = -2;
     if (v == -2) { const char* e = getenv("DALI_CONV_CFG"); v = e ? atoi(e) : -1; }
@@ -957,6 +1041,7 @@ int conv_pick_cfg(int Cm, int P, int K) {
     if (ov == 0 || ov == 1) return CONV_128;
     if (ov == 4) return Cm >= 256 ? CONV_256x256 : CONV_128;
     if (ov == 6) return Cm >= 256 ? CONV_128x256 : CONV_128;
+    if (ov == 7) return Cm >= 256 ? CONV_256x128 : CONV_128;
     if (K >= 1024 && P >= 16384) {
         if (Cm >= 512) return CONV_256x256;
         if (Cm >= 256) return CONV_128x256;
@@ -965,7 +1050,7 @@ int conv_pick_cfg(int Cm, int P, int K) {
 }
 int igemm_conv_stat_tiles(int Cm, int P, int K) {
     const int c = conv_pick_cfg(Cm, P, K);
-    return (c == CONV_128) ? (P + 127) / 128 : (P + 255) / 256;
+    return (c == CONV_128 || c == CONV_256x128) ? (P + 127) / 128 : (P + 255) / 256;
 }
 
 
@@ -1048,7 +1133,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const bool dma_ok = !in_bn && x_bytes < 0x7ff00000ll && (long long)a.Cm * a.g.R * a.g.S * a.g.Ck * 2 < 0x7ff00000ll;
     const int K = a.g.nr * a.g.ns * a.g.Ck;               // reduction length actually visited
     const int cfg = conv_pick_cfg(a.Cm, a.P, K);
-    if (!dma_ok && !in_bn && a.stats && (cfg == CONV_128x256 || cfg == CONV_256x256)) {
+    if (!dma_ok && !in_bn && a.stats && (cfg == CONV_128x256 || cfg == CONV_256x256 || cfg == CONV_256x128)) {
         set_error("conv: tensors beyond 2 GiB are not supported together with the BatchNorm statistics epilogue");
         return DALI_ERR_LIMIT;
     }
@@ -1067,6 +1152,12 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         const int lds = (256 + 256) * 32 * 2 * 4;
         if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
         hipLaunchKernelGGL((igemm_conv_wg_kernel<4, 4, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+    } else if (!in_bn && dma_ok && cfg == CONV_256x128) {
+        static bool attr_set = false;
+        const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 127) / 128;
+        const int lds = (256 + 128) * 32 * 2 * 3;
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_conv_wg_kernel<4, 2, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else if (!in_bn && dma_ok && cfg == CONV_128x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;

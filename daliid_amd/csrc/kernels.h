@@ -34,7 +34,7 @@ struct IGemmArgs {
     int act;                  // 0 none, 1 exact-erf GELU (vit_pytorch.py:120-136 nn.GELU)
     int Cm, P, in_relu;
     GatherGeom g;
-    unsigned long long* stamps;   // diagnostic (dali_debug_set_conv_stamps): [block][4] s_memrealtime at start / first tile landed / mainloop done / end
+    unsigned long long* stamps;   // diagnostic (dali_debug_set_conv_stamps): [block][12] s_memrealtime stamps (see scripts/conv_block_timeline.py)
 };
 
 struct WGradArgs {

@@ -9,24 +9,29 @@ x = torch.randn(B, H, W, cin, device="cuda").to(bf16)
 w = torch.randn(cout, k, k, cin, device="cuda").to(bf16)
 for _ in range(3): nn.conv2d_fwd(x, w, 1, k // 2, want_stats=True)
 nblk = 1 << 16
-stamps = torch.zeros(nblk, 4, device="cuda", dtype=torch.int64)
+stamps = torch.zeros(nblk, 12, device="cuda", dtype=torch.int64)
 L = _lib.lib(); L.dali_debug_set_conv_stamps.argtypes = [ctypes.c_void_p]
 L.dali_debug_set_conv_stamps(ctypes.c_void_p(stamps.data_ptr()))
 nn.conv2d_fwd(x, w, 1, k // 2, want_stats=True)
 torch.cuda.synchronize()
 L.dali_debug_set_conv_stamps(None)
 s = stamps.cpu().numpy()
-s = s[s[:, 0] > 0]
+s = s[s[:, 3] > 0].astype(np.float64)
 t0 = s[:, 0].min()
-s = (s - t0) * 10.0 / 1e3           # 100 MHz ticks -> us
-print("blocks stamped: %d ; kernel span %.1f us" % (len(s), s[:, 3].max()))
+s = np.where(s > 0, (s - t0) * 10.0 / 1e3, np.nan)           # 100 MHz ticks -> us
+span = np.nanmax(s[:, 3])
+print("blocks stamped: %d ; kernel span %.1f us" % (len(s), span))
 d = s[:, 3] - s[:, 0]
 print("block lifetime us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % (d.mean(), *np.percentile(d, [10, 50, 90]), d.max()))
-print("  start->first tile landed: mean %.2f us ; mainloop: mean %.2f ; epilogue+stores: mean %.2f" %
-      ((s[:, 1] - s[:, 0]).mean(), (s[:, 2] - s[:, 1]).mean(), (s[:, 3] - s[:, 2]).mean()))
-print("  mean concurrency = sum(lifetime)/span = %.1f blocks (256 CUs)" % (d.sum() / s[:, 3].max()))
-edges = np.linspace(0, s[:, 3].max(), 11)
-for a, b in zip(edges[:-1], edges[1:]):
-    alive = ((s[:, 0] < b) & (s[:, 3] > a)).sum()
-    started = ((s[:, 0] >= a) & (s[:, 0] < b)).sum()
-    print("  t %6.1f-%6.1f us: %5d blocks started, %5d alive at some point" % (a, b, started, alive))
+names = ["start", "first tile landed", "mainloop done", "end (stores acked)", "all stores issued", "stats done", "half0 staged", "half0 stores issued",
+         "half1 staged", "half1 stores issued"]
+order = [0, 1, 2, 5, 6, 7, 8, 9, 4, 3]
+prev = None
+for k in order:
+    col = s[:, k]
+    if np.isnan(col).all():
+        continue
+    if prev is not None:
+        print("  %-22s -> %-22s mean %6.2f us" % (names[prev], names[k], np.nanmean(col - s[:, prev])))
+    prev = k
+print("  mean concurrency = sum(lifetime)/span = %.1f blocks (256 CUs)" % (d.sum() / span))
