@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kerne
 
     // wave-uniform k position
     int kr = g.r0, ks = g.s0, kc0 = 0;
-    const int ks_end = g.s0 + g.sstep * g.ns;
+    const int ks_end = g.s0 + g.sstep * g.ns, kr_end = g.r0 + g.rstep * g.nr;
     auto issue = [&](int stage) {
         uint16_t* sa = smem + stage * Cfg::STAGE_ELEMS;
         uint16_t* sb = sa + Cfg::A_ELEMS;
@@ -429,8 +429,11 @@ __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kerne
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + 4 * i) * 512), 16, off, 0, 0, 0);
         }
         // advance (channel block fastest, then s, then r)
-        kc0 += 32;
-        if (kc0 == g.Ck) { kc0 = 0; ks += g.sstep; if (ks >= ks_end) { ks = g.s0; kr += g.rstep; } }
+        // taps fastest, channel block outermost: the R*S taps of one channel block are fetched in consecutive k-steps, so the
+        // shifted re-reads of the same pixels hit the XCD's L2 (channels-fastest order spaced them Ck/32 steps apart: with
+        // Ck >= 128 the line had left the 4 MiB L2 and came back from the Infinity Cache at HBM-like bandwidth, 9 times)
+        ks += g.sstep;
+        if (ks >= ks_end) { ks = g.s0; kr += g.rstep; if (kr >= kr_end) { kr = g.r0; kc0 += 32; } }
     };
 
     f32x4_t acc[FM][FN];
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
         b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;
     }
     int kr = g.r0, ks = g.s0, kc0 = 0;
-    const int ks_end = g.s0 + g.sstep * g.ns;
+    const int ks_end = g.s0 + g.sstep * g.ns, kr_end = g.r0 + g.rstep * g.nr;
     auto issue = [&](int stage) {
         uint16_t* sa = smem + stage * STAGE_ELEMS;
         uint16_t* sb = sa + A_ELEMS;
@@ -555,8 +558,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
             const uint32_t off = ok ? (uint32_t)(b_pix[i] + hi * g.row_pitch + wi * g.pix_pitch + kc0) * 2u : DMA_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + NW * i) * 512), 16, off, 0, 0, 0);
         }
-        kc0 += 32;
-        if (kc0 == g.Ck) { kc0 = 0; ks += g.sstep; if (ks >= ks_end) { ks = g.s0; kr += g.rstep; } }
+        // taps fastest, channel block outermost: the R*S taps of one channel block are fetched in consecutive k-steps, so the
+        // shifted re-reads of the same pixels hit the XCD's L2 (channels-fastest order spaced them Ck/32 steps apart: with
+        // Ck >= 128 the line had left the 4 MiB L2 and came back from the Infinity Cache at HBM-like bandwidth, 9 times)
+        ks += g.sstep;
+        if (ks >= ks_end) { ks = g.s0; kr += g.rstep; if (kr >= kr_end) { kr = g.r0; kc0 += 32; } }
     };
     f32x4_t acc[4][4];
 #pragma unroll
@@ -750,6 +756,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
     const int ks = item / tiles, tile = item - ks * tiles;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * 128, n0 = tn * 128;
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
     const GatherGeom g = a.g;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
     const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
@@ -804,6 +811,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
         if (ksteps > 1) issue(1, 1);
         if (ksteps > 1) dma_wait<4>(); else dma_wait<0>();
         __builtin_amdgcn_s_barrier();
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
         int st_cur = 0, st_nxt2 = 2;
         for (int kt = 0; kt < ksteps; ++kt) {
             if (kt + 2 < ksteps) issue(kt + 2, st_nxt2);
@@ -824,6 +832,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
             st_nxt2 = (st_nxt2 == 2) ? 0 : st_nxt2 + 1;
         }
     }
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
     float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -836,6 +845,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
                 if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
             }
         }
+    if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
+    }
 }
 
 // wgrad, wave-grid variant: WM x WN waves of 64 x 64 sub-tiles; the (64*WM) x (64*WN) block tile is held as (TM+TN)/128
@@ -1180,21 +1194,26 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
 
 // Chooses the split count so that the grid has ~target blocks; returns slab bytes through *ws_bytes.
 // 0: 128x128 (4 waves); 1: 256x256 (16 waves, 4-deep ring) for the large weight matrices
-int wgrad_pick_cfg(int Cm, int Ntot) {
+// Tile shape of the weight-gradient GEMM (measured per layer, scripts/bench_convs.py): 0 = 128 x 128 / 4 waves,
+// 1 = 256 x 256 / 16 waves, 2 = 128 x 256 / 8 waves.  The wider tiles cut the L2 -> LDS operand bytes per FLOP and win
+// on the 1x1 layers with a long pixel (K) dimension; on 3x3 layers (each 128-column group of N is one tap's gather)
+// and on the ViT linears (25 k rows: the split-K slabs double) they lose.
+int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P) {
     static int ov = -2;
     if (ov == -2) { const char* e = getenv("DALI_WGRAD_CFG"); ov = e ? atoi(e) : -1; }
+    if (ov == 2) return (Ntot >= 256) ? 2 : 0;
     if (ov >= 0) return (ov == 1 && Cm >= 256 && Ntot >= 256) ? 1 : 0;
-    // measured (r01): the 16-wave tile wins on the wide 1x1 layers of layer4 and loses on the 3x3 (Ntot = 9 Cin) ones
-    return (Cm >= 512 && Ntot >= 512 && Ntot <= 2048) ? 1 : 0;
+    return (taps == 1 && Ntot >= 256 && P >= 32768) ? 2 : 0;
 }
-void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes) {
+void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps) {
     static int target_override = -2;
     if (target_override == -2) { const char* e = getenv("DALI_WGRAD_TARGET"); target_override = e ? atoi(e) : -1; }
     if (target_override > 0) target_blocks = target_override;
-    const int big = wgrad_pick_cfg(Cm, Ntot);
-    const int T = big ? 256 : 128;
-    if (big) target_blocks = 256;                   // one 16-wave block per CU
-    const int tiles = ((Cm + T - 1) / T) * ((Ntot + T - 1) / T);
+    const int cfg = wgrad_pick_cfg(Cm, Ntot, taps, P);
+    const int TMc = cfg == 1 ? 256 : 128, TNc = cfg == 0 ? 128 : 256;
+    if (cfg == 1) target_blocks = 256;              // one 16-wave block per CU
+    if (cfg == 2) target_blocks = 512;              // two 8-wave blocks per CU
+    const int tiles = ((Cm + TMc - 1) / TMc) * ((Ntot + TNc - 1) / TNc);
     int sp = (target_blocks + tiles - 1) / tiles;
     const int max_sp = (P + 255) / 256;              // at least 8 k-steps per block
     if (sp > max_sp) sp = max_sp;
@@ -1207,6 +1226,7 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
 
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate) {
     WGradArgs args = a;
+    args.stamps = g_conv_stamps;
     args.g.lw = ilog2_exact(a.g.Wout);
     args.g.lhw = ilog2_exact(a.g.Hout * a.g.Wout);
     const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.Ntot + 127) / 128;
@@ -1215,12 +1235,19 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const bool dma_ok = x_bytes < 0x7ff00000ll && (long long)a.P * a.Cm * 2 < 0x7ff00000ll;
     {
     ProfScope prof_scope(st, 1, 2.0 * a.Cm * (double)a.Ntot * a.P);
-    if (!a.in_scale && dma_ok && wgrad_pick_cfg(a.Cm, a.Ntot) == 1) {
+    const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P);
+    if (!a.in_scale && dma_ok && wcfg == 1) {
         static bool attr_set = false;
         const int tm2 = (a.Cm + 255) / 256, tn2 = (a.Ntot + 255) / 256;
         const int lds = 4 * 4 * 32 * 128 * 2;       // 4 stages x 4 images x 8 KiB
         if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
         hipLaunchKernelGGL((igemm_wgrad_wg_kernel<4, 4, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds, st, args, tm2, tn2);
+    } else if (!a.in_scale && dma_ok && wcfg == 2) {
+        static bool attr_set = false;
+        const int tm2 = (a.Cm + 127) / 128, tn2 = (a.Ntot + 255) / 256;
+        const int lds = 3 * 3 * 32 * 128 * 2;       // 3 stages x 3 images x 8 KiB
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm2, tn2);
     } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
@@ -1329,7 +1356,7 @@ extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
     a.Cm = cout; a.P = n * ho * wo; a.Ntot = r * s * cin;
     fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
     size_t ws_bytes;
-    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &ws_bytes);
+    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &ws_bytes, r * s);
     a.partial = static_cast<float*>(workspace(ctx, ws_bytes));
     if (!a.partial) return DALI_ERR_NOMEM;
     return launch_igemm_wgrad((hipStream_t)stream, a, dw, accumulate);

@@ -45,6 +45,7 @@ struct WGradArgs {
     int Cm, P, Ntot, in_relu;
     int splits, pix_per_split;    // pix_per_split multiple of 32
     GatherGeom g;
+    unsigned long long* stamps;   // diagnostic, as in IGemmArgs
 };
 
 
@@ -53,7 +54,8 @@ struct BnBwdSide { const uint16_t* raw; const float* mean; const float* invstd; 
 // conv.hip
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a);
 int igemm_conv_stat_tiles(int Cm, int P, int K);
-void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes);
+// taps = R*S of the convolution (1 for 1x1 convolutions and linear layers): selects the tile shape
+void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps = 1);
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
 
 int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,

@@ -233,7 +233,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             const int P = (int)N * c->hout * c->wout;
             max_stat = std::max(max_stat, (size_t)igemm_conv_stat_tiles(c->cout, P, c->r * c->s * c->cin) * c->cout * 2 * 4);
             int sp, pps; size_t wsb;
-            wgrad_plan(c->cout, c->r * c->s * c->cin, P, 512, &sp, &pps, &wsb);
+            wgrad_plan(c->cout, c->r * c->s * c->cin, P, 512, &sp, &pps, &wsb, c->r * c->s);
             max_slab = std::max(max_slab, wsb);
             max_act = std::max(max_act, (size_t)P * c->cout * 2);
             max_act = std::max(max_act, N * c->hin * c->win * c->cin * 2);
@@ -359,7 +359,7 @@ int conv_wgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* 
     a.Cm = c.cout; a.P = net->N * c.hout * c.wout; a.Ntot = c.r * c.s * c.cin;
     a.g = conv_geom(c, 0);
     size_t wsb;
-    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb);
+    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb, c.r * c.s);
     return launch_igemm_wgrad(st, a, net->G + c.w_off, 0);
 }
 

@@ -5,14 +5,17 @@ import numpy as np, torch
 from daliid_amd import ops_nn as nn, _lib
 bf16 = torch.bfloat16
 B, H, W, cin, cout, k = [int(v) for v in sys.argv[1:7]] if len(sys.argv) > 6 else (256, 64, 32, 64, 256, 1)
+MODE = sys.argv[7] if len(sys.argv) > 7 else "fwd"
 x = torch.randn(B, H, W, cin, device="cuda").to(bf16)
 w = torch.randn(cout, k, k, cin, device="cuda").to(bf16)
-for _ in range(3): nn.conv2d_fwd(x, w, 1, k // 2, want_stats=True)
+dy = torch.randn(B, H, W, cout, device="cuda").to(bf16)
+run = (lambda: nn.conv2d_fwd(x, w, 1, k // 2, want_stats=True)) if MODE == "fwd" else (lambda: nn.conv2d_wgrad(x, dy, (k, k), 1, k // 2))
+for _ in range(3): run()
 nblk = 1 << 16
 stamps = torch.zeros(nblk, 12, device="cuda", dtype=torch.int64)
 L = _lib.lib(); L.dali_debug_set_conv_stamps.argtypes = [ctypes.c_void_p]
 L.dali_debug_set_conv_stamps(ctypes.c_void_p(stamps.data_ptr()))
-nn.conv2d_fwd(x, w, 1, k // 2, want_stats=True)
+run()
 torch.cuda.synchronize()
 L.dali_debug_set_conv_stamps(None)
 s = stamps.cpu().numpy()
