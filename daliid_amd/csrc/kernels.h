@@ -49,6 +49,10 @@ struct WGradArgs {
 };
 
 
+// one [Co][T][Ci] -> [Ci][T][Co] bf16 weight transpose (dgrad image); first_block is filled by the launcher
+struct TransposeJob { const uint16_t* w; uint16_t* wt; int Co, T, Ci, first_block; };
+int launch_weight_transpose_batched(hipStream_t st, const TransposeJob* jobs, int n);
+
 struct BnBwdSide { const uint16_t* raw; const float* mean; const float* invstd; const float* scale; const float* shift; };
 
 // conv.hip

@@ -466,52 +466,74 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// BatchNorm1d neck on fp32 [N,C] (one thread per channel; N rows are L2 resident).
+// BatchNorm1d neck on fp32 [N,C].
 // ------------------------------------------------------------------------------------------------
+// block = 32 channels x 8 row slices (thread: channel tid&31, rows tid>>5, +8, ...); fp64 partial sums, slices added in a
+// fixed order.  (A single thread per channel walking all N rows was latency-bound: 120 us for a 2 MB tensor.)
+__device__ __forceinline__ double bn1d_slice_sum(double v, double (*red)[32]) {
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    __syncthreads();                                   // previous use of red is over
+    red[ry][cx] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][cx];
+    return s;
+}
 __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int N, int C, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
                                                         int training, float momentum, float eps, float* __restrict__ y,
                                                         float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float mean, invstd;
+    __shared__ double red[8][32];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const bool ok = c < C;
+    float mean = 0.f, invstd = 1.f;
     if (training) {
         double s = 0.0;
-        for (int n = 0; n < N; ++n) s += (double)x[(size_t)n * C + c];
-        const double m = s / N;
+        if (ok) for (int n = ry; n < N; n += 8) s += (double)x[(size_t)n * C + c];
+        const double m = bn1d_slice_sum(s, red) / N;
         double v = 0.0;
-        for (int n = 0; n < N; ++n) { const double d = (double)x[(size_t)n * C + c] - m; v += d * d; }
+        if (ok) for (int n = ry; n < N; n += 8) { const double d = (double)x[(size_t)n * C + c] - m; v += d * d; }
+        v = bn1d_slice_sum(v, red);
         const double var = v / N;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
-        if (rm) {
+        if (rm && ok && ry == 0) {
             const double unbiased = N > 1 ? v / (N - 1) : var;
             rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
             rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
         }
-    } else {
+    } else if (ok) {
         mean = rm[c];
         invstd = 1.0f / sqrtf(rv[c] + eps);
     }
-    if (mean_out) { mean_out[c] = mean; invstd_out[c] = invstd; }
+    if (!ok) return;
+    if (mean_out && ry == 0) { mean_out[c] = mean; invstd_out[c] = invstd; }
     const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
-    for (int n = 0; n < N; ++n) y[(size_t)n * C + c] = x[(size_t)n * C + c] * sc + sh;
+    for (int n = ry; n < N; n += 8) y[(size_t)n * C + c] = x[(size_t)n * C + c] * sc + sh;
 }
 __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ dx,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float m = mean[c], iv = invstd[c];
+    __shared__ double red[8][32];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const bool ok = c < C;
+    const float m = ok ? mean[c] : 0.f, iv = ok ? invstd[c] : 1.f;
     double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const float g = dy[(size_t)n * C + c];
-        s1 += (double)g; s2 += (double)g * (double)((x[(size_t)n * C + c] - m) * iv);
-    }
-    dgamma[c] = (float)s2; dbeta[c] = (float)s1;
+    if (ok)
+        for (int n = ry; n < N; n += 8) {
+            const float g = dy[(size_t)n * C + c];
+            s1 += (double)g; s2 += (double)g * (double)((x[(size_t)n * C + c] - m) * iv);
+        }
+    s1 = bn1d_slice_sum(s1, red);
+    s2 = bn1d_slice_sum(s2, red);
+    if (!ok) return;
+    if (ry == 0) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }
     const float a = (float)(s1 / N), b = (float)(s2 / N), sc = gamma[c] * iv;
-    for (int n = 0; n < N; ++n) {
+    for (int n = ry; n < N; n += 8) {
         const float xh = (x[(size_t)n * C + c] - m) * iv;
         dx[(size_t)n * C + c] = sc * (dy[(size_t)n * C + c] - a - xh * b);
     }
@@ -546,6 +568,30 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const uint16_t* _
     for (int y = y0; y < 32; y += 8) {
         const int ci = tci * 32 + y, co = tco * 32 + x;
         if (ci < Ci && co < Co) wt[((size_t)ci * T + tap) * Co + co] = tile[x][y];
+    }
+}
+
+// all dgrad weight images of a net in one launch: the job table travels as a kernel argument
+constexpr int TRANSPOSE_BATCH = 56;
+struct TransposeBatch { TransposeJob job[TRANSPOSE_BATCH]; int n; };
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(TransposeBatch batch) {
+    __shared__ uint16_t tile[32][33];
+    int ji = 0;
+    while (ji + 1 < batch.n && (int)blockIdx.x >= batch.job[ji + 1].first_block) ++ji;       // block-uniform scan
+    const TransposeJob jb = batch.job[ji];
+    const int Co = jb.Co, T = jb.T, Ci = jb.Ci;
+    const int tiles_ci = (Ci + 31) / 32, tiles_co = (Co + 31) / 32;
+    const int b = blockIdx.x - jb.first_block;
+    const int tci = b % tiles_ci, tco = (b / tiles_ci) % tiles_co, tap = b / (tiles_ci * tiles_co);
+    const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;
+    for (int y = y0; y < 32; y += 8) {
+        const int co = tco * 32 + y, ci = tci * 32 + x;
+        tile[y][x] = (co < Co && ci < Ci) ? jb.w[((size_t)co * T + tap) * Ci + ci] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int y = y0; y < 32; y += 8) {
+        const int ci = tci * 32 + y, co = tco * 32 + x;
+        if (ci < Ci && co < Co) jb.wt[((size_t)ci * T + tap) * Co + co] = tile[x][y];
     }
 }
 
@@ -696,19 +742,34 @@ int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, in
 }
 int launch_bn1d_fwd(hipStream_t st, const float* x, int N, int C, const float* gamma, const float* beta, float* rm, float* rv, int training,
                     float momentum, float eps, float* y, float* mean, float* invstd) {
-    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, N, C, gamma, beta, rm, rv, training, momentum, eps, y, mean, invstd);
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((C + 31) / 32), dim3(256), 0, st, x, N, C, gamma, beta, rm, rv, training, momentum, eps, y, mean, invstd);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 int launch_bn1d_bwd(hipStream_t st, const float* x, const float* dy, int N, int C, const float* gamma, const float* mean, const float* invstd,
                     float* dx, float* dgamma, float* dbeta) {
-    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, dy, N, C, gamma, mean, invstd, dx, dgamma, dbeta);
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, st, x, dy, N, C, gamma, mean, invstd, dx, dgamma, dbeta);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 int launch_cast_bf16(hipStream_t st, const float* x, size_t n, uint16_t* y) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, st, x, n, y);
     DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_weight_transpose_batched(hipStream_t st, const TransposeJob* jobs, int n) {
+    for (int begin = 0; begin < n; begin += TRANSPOSE_BATCH) {
+        TransposeBatch batch{};
+        batch.n = n - begin < TRANSPOSE_BATCH ? n - begin : TRANSPOSE_BATCH;
+        int blocks = 0;
+        for (int i = 0; i < batch.n; ++i) {
+            batch.job[i] = jobs[begin + i];
+            batch.job[i].first_block = blocks;
+            blocks += ((batch.job[i].Ci + 31) / 32) * ((batch.job[i].Co + 31) / 32) * batch.job[i].T;
+        }
+        hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3(blocks), dim3(256), 0, st, batch);
+        DALI_LAUNCH_CHECK();
+    }
     return DALI_OK;
 }
 int launch_weight_transpose(hipStream_t st, const uint16_t* w, int Co, int T, int Ci, uint16_t* wt) {

@@ -317,15 +317,13 @@ extern "C" int dali_resnet_refresh_weights(dali_resnet* net, void* stream) {
     if (rc) return rc;
     rc = launch_stem_pack_weight(st, net->P + net->stem.w_off, net->stem.cout, net->w_stem);
     if (rc) return rc;
+    std::vector<TransposeJob> jobs;                      // every conv's dgrad image [cin][r*s][cout], one launch
     for (auto& b : net->blocks) {
         Conv* cs[4] = {&b.c1, &b.c2, &b.c3, b.has_ds ? &b.cd : nullptr};
-        for (Conv* c : cs) {
-            if (!c) continue;
-            rc = launch_weight_transpose(st, c->w_bf16, c->cout, c->r * c->s, c->cin, c->wt_bf16);
-            if (rc) return rc;
-        }
+        for (Conv* c : cs)
+            if (c) jobs.push_back(TransposeJob{c->w_bf16, c->wt_bf16, c->cout, c->r * c->s, c->cin, 0});
     }
-    return DALI_OK;
+    return launch_weight_transpose_batched(st, jobs.data(), (int)jobs.size());
 }
 
 namespace {
