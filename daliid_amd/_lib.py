@@ -73,6 +73,8 @@ _SIGNATURES = {
                             c_void_p, c_void_p],
     "dali_class_targets": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                            c_void_p, c_void_p],
+    "dali_resize_bicubic_u8": [c_void_p] * 7 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dali_augment_batch": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p],
     "dali_gemm_profile_begin": [c_void_p, c_int],
     "dali_gemm_profile_end": [c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_resnet_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],

@@ -16,6 +16,20 @@ from .losses import LossHeads, _codes, _sample_weights
 np.random.seed(12)
 torch.manual_seed(12)
 
+_train_loader = None
+
+
+def set_train_loader(fn):
+    """fn(paths, img_height, img_width, turb=None) -> float tensor [n,3,H,W]: the loader ``samplePKBatches`` uses, i.e.
+    decode + the training transform of train_encodersKIT.py:313-320 (``daliid_amd.transforms.gpu_train_loader`` runs it
+    on the GPU).  None: fall back to the evaluation loader of daliid_amd.getFeatures (resize + normalise, no augmentation)."""
+    global _train_loader
+    _train_loader = fn
+
+
+def get_train_loader():
+    return _train_loader if _train_loader is not None else get_image_loader()
+
 
 def selectProxiesByTriagulation(X, num_proxies=5):
     """train_encodersKIT.py:252-284: farthest-point sampling; first pick ``np.random.choice(n)``, then repeatedly the
@@ -80,7 +94,7 @@ class samplePKBatches:
         pid = self.labels_set[idx]
         names = self.images_names[self.labels == pid]
         sel = np.random.choice(names.shape[0], size=min(names.shape[0], self.K), replace=False)
-        loader = get_image_loader()
+        loader = get_train_loader()
         clean = loader(list(names[sel]), self.img_height, self.img_width, None)
         if self.kind_of_transform == 0:
             imgs, dist = clean, np.zeros(len(sel), dtype=np.int32)

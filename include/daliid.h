@@ -261,6 +261,26 @@ int dali_class_targets(dali_ctx* ctx, void* stream, const float* fvs, int n, int
                        const int32_t* bounds, int n_classes, const int32_t* first_pick, int num_proxies,
                        float* centers, float* proxies, int32_t* proxy_rows, float* max_dist);
 
+/* ---- input pipeline on decoded uint8 images (decode stays on the host) -------------------------- *
+ * Resize((H,W), bicubic) of getFeatures.py:18 / train_encodersKIT.py:313 = Pillow's two-pass ImagingResample on 8-bit
+ * data, reproduced bit for bit: src = n packed RGB images [in_h][in_w][3] at byte offsets src_off; table_of[n] selects
+ * the coefficient table of the image's size; bounds_* [tables][out][2] = (first input index, tap count) and coefs_*
+ * [tables][out][ksize] = 22-bit fixed-point taps, built by the host as Pillow's precompute_coeffs does
+ * (daliid_amd/transforms.py).  out = [n][out_h][out_w][3] uint8.  All pointers are device pointers. */
+int dali_resize_bicubic_u8(dali_ctx* ctx, void* stream, const uint8_t* src, const int64_t* src_off, const int32_t* in_h,
+                           const int32_t* in_w, const int32_t* table_of, int n, int max_in_h, const int32_t* bounds_h,
+                           const int32_t* coefs_h, int ksize_h, const int32_t* bounds_v, const int32_t* coefs_v, int ksize_v,
+                           int out_h, int out_w, uint8_t* out);
+/* RandomCrop(padding) -> RandomHorizontalFlip -> ColorJitter(brightness, contrast, saturation) -> ToTensor ->
+ * RandomErasing(value 0) -> Normalize (train_encodersKIT.py:313-320) of n resized uint8 images [n][h][w][3] with the
+ * per-image parameters drawn by the host in torchvision's order: params [n][16] int32 words = crop top, crop left,
+ * flip, 4 x op order (0 brightness, 1 contrast, 2 saturation, 3 hue = no-op), erase i, j, h, w (h = 0: none), the
+ * three factors as float bits, crop padding, augment flag (0 = eval path: ToTensor + Normalize only,
+ * getFeatures.py:18-19).  The enhancers follow PIL.ImageEnhance on 8-bit data exactly.  mean3 / std3 are HOST pointers
+ * to 3 floats; out = fp32 [n][3][h][w].  One workgroup per image, the image lives in LDS (h*w*3 <= 150 KiB). */
+int dali_augment_batch(dali_ctx* ctx, void* stream, const uint8_t* images, const int32_t* params, int n, int h, int w,
+                       const float* mean3, const float* std3, float* out);
+
 /* ---- measurement aid (bench.py roofline leg; no reference counterpart) ------------------------------- *
  * Between _begin and _end every MFMA GEMM kernel launch of the conv / linear path (class 0: igemm_conv_*
  * forward + dgrad, class 1: igemm_wgrad_*) is bracketed by two HIP events on the stream it is launched on.
