@@ -444,7 +444,7 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     // y = relu(bn3(raw3) + identity): dz = dy*(y>0) written in place over dy
     rc = launch_bn_bwd(st, dy, nullptr, b.ybits, s3, b.has_ds ? &sd : nullptr, 1, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
                        net->G + b.b3.g_off, net->G + b.b3.b_off, b.has_ds ? net->G + b.bd.g_off : nullptr, b.has_ds ? net->G + b.bd.b_off : nullptr,
-                       d_raw3, d_rawd, dy, net->red_scratch);
+                       d_raw3, d_rawd, b.has_ds ? nullptr : dy, net->red_scratch);   // dz only feeds the identity path (no downsample)
     if (rc) return rc;
     uint16_t* dz = dy;
     // conv3
