@@ -54,8 +54,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
         double a = 0.0, b = 0.0;
-#pragma unroll 8
-        for (int t = 0; t < tiles; ++t) {
+        int t = 0;
+        for (; t + 8 <= tiles; t += 8) {                  // 8 loads in flight (tiles goes up to REDUCE_SMAX = 64)
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(partial + ((size_t)(t + u) * C + c) * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
+        }
+        for (; t < tiles; ++t) {
             const double2 v = *reinterpret_cast<const double2*>(partial + ((size_t)t * C + c) * 2);
             a += v.x; b += v.y;
         }
@@ -209,8 +216,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
         double a = 0.0, b = 0.0;
-#pragma unroll 8
-        for (int t = 0; t < blocks; ++t) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
+        int t = 0;
+        for (; t + 8 <= blocks; t += 8) {                 // 8 x 2 loads in flight
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const double* p = partial + ((size_t)(t + u) * C + c) * NV; va[u] = p[0]; vb[u] = p[which]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; t < blocks; ++t) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
         const double sc = (double)scale[c];
         const double q = sc * (double)invstd[c] * (b / count);
         coef[c] = scale[c];

@@ -239,9 +239,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __r
 __global__ void finish_sum_kernel(const double* __restrict__ scratch, int S, int cols, int stride, int which, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
-    double a = 0.0;
-    for (int s = 0; s < S; ++s) a += scratch[(size_t)s * cols * stride + (size_t)c * stride + which];
-    out[c] = (float)a;
+    const double* p = scratch + (size_t)c * stride + which;
+    const size_t pitch = (size_t)cols * stride;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // 8 loads in flight (S goes up to 64)
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * pitch];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += v[u];
+    }
+    for (; s < S; ++s) a[0] += p[(size_t)s * pitch];
+    out[c] = (float)(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -393,17 +403,21 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __re
     for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += 256) {
         sQ[ATT_TP * ATT_LD + i] = 0; sK[ATT_TP * ATT_LD + i] = 0; sV[ATT_TP * ATT_LD + i] = 0; sD[ATT_TP * ATT_LD + i] = 0;
     }
-    // D_i = sum_d dO[i][d] * O[i][d]; lse
-    for (int i = threadIdx.x; i < ATT_PK; i += 256) {
+    // D_i = sum_d dO[i][d] * O[i][d] (8 lanes x 16 bytes per row, coalesced; reduced over the 8 lanes); lse
+    for (int i0 = 0; i0 < ATT_PK; i0 += 32) {
+        const int i = i0 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
         float acc = 0.f;
         if (i < T) {
-            const uint16_t* orow = o + ((size_t)b * T + i) * C + h * ATT_HD;
-            const uint16_t* grow = d_o + ((size_t)b * T + i) * C + h * ATT_HD;
-            for (int d = 0; d < ATT_HD; ++d) acc += bf16_bits_to_f32(orow[d]) * bf16_bits_to_f32(grow[d]);
+            float ov[8], gv[8];
+            unpack8v(*reinterpret_cast<const uint4*>(o + ((size_t)b * T + i) * C + h * ATT_HD + ch * 8), ov);
+            unpack8v(*reinterpret_cast<const uint4*>(d_o + ((size_t)b * T + i) * C + h * ATT_HD + ch * 8), gv);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc += ov[d] * gv[d];
         }
-        sDi[i] = acc;
-        sLse[i] = (i < T) ? lse[(size_t)bh * T + i] : 0.f;
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (ch == 0 && i < ATT_PK) sDi[i] = acc;
     }
+    for (int i = threadIdx.x; i < ATT_PK; i += 256) sLse[i] = (i < T) ? lse[(size_t)bh * T + i] : 0.f;
     __syncthreads();
     uint16_t* myP = sP + wave * 16 * ATT_PK;
     for (int i = lane; i < 16 * (ATT_PK - ATT_TP); i += 64) myP[(i / 16) * ATT_PK + ATT_TP + (i & 15)] = 0;
@@ -413,22 +427,24 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __re
         if (qt * 16 >= T) break;
         const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
         const bf16x8_t ga0 = frag_k(sD, ATT_LD, qt * 16, 0, lane), ga1 = frag_k(sD, ATT_LD, qt * 16, 32, lane);
-        float lrow[4], drow[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { lrow[r] = sLse[qt * 16 + (lane >> 4) * 4 + r]; drow[r] = sDi[qt * 16 + (lane >> 4) * 4 + r]; }
+        // score tiles are computed TRANSPOSED (rows = keys, columns = this tile's queries): a lane then holds 4 consecutive
+        // keys of one query = one 8-byte write into the [query][key] strip (the un-transposed form needed four 2-byte writes)
+        const float lq = sLse[qt * 16 + (lane & 15)] * 1.44269504088896f, dq_i = sDi[qt * 16 + (lane & 15)], sc2 = scale * 1.44269504088896f;
 #pragma unroll
         for (int j = 0; j < ATT_TP / 16; ++j) {
             f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(sK, ATT_LD, j * 16, 0, lane), s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(sK, ATT_LD, j * 16, 32, lane), s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, frag_k(sV, ATT_LD, j * 16, 0, lane), dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga1, frag_k(sV, ATT_LD, j * 16, 32, lane), dp, 0, 0, 0);
-            const bool valid = j * 16 + (lane & 15) < T;
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 0, lane), ga0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 32, lane), ga1, dp, 0, 0, 0);
+            const int key0 = j * 16 + (lane >> 4) * 4;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = valid ? expf(s[r] * scale - lrow[r]) : 0.f;
-                myP[((lane >> 4) * 4 + r) * ATT_PK + j * 16 + (lane & 15)] = f32_to_bf16_bits(p * (dp[r] - drow[r]) * scale);
+                const float p = (key0 + r < T) ? __builtin_amdgcn_exp2f(s[r] * sc2 - lq) : 0.f;
+                v[r] = p * (dp[r] - dq_i) * scale;
             }
+            *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_PK + key0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
         f32x4_t dq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -456,22 +472,26 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __re
         for (int sweep = 0; sweep < 2; ++sweep) {
 #pragma unroll
             for (int j = 0; j < ATT_TP / 16; ++j) {                 // query tile j
+                // rows = queries of tile j, columns = this tile's keys: 4 consecutive queries of one key per lane = one
+                // 8-byte write into the [key][query] strip
                 f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, frag_k(sQ, ATT_LD, j * 16, 0, lane), st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, frag_k(sQ, ATT_LD, j * 16, 32, lane), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 0, lane), ka0, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 32, lane), ka1, st, 0, 0, 0);
                 if (sweep == 1) {
-                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, frag_k(sD, ATT_LD, j * 16, 0, lane), dpt, 0, 0, 0);
-                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, frag_k(sD, ATT_LD, j * 16, 32, lane), dpt, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 0, lane), va0, dpt, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 32, lane), va1, dpt, 0, 0, 0);
                 }
-                const int qi = j * 16 + (lane & 15);               // query index = column
-                const float lq = sLse[qi], dq_i = sDi[qi];
+                const int q0 = j * 16 + (lane >> 4) * 4;           // first of this lane's 4 queries
+                const bool key_ok = kt * 16 + (lane & 15) < T;
+                const float4 lq4 = *reinterpret_cast<const float4*>(sLse + q0), dq4 = *reinterpret_cast<const float4*>(sDi + q0);
+                const float lqv[4] = {lq4.x, lq4.y, lq4.z, lq4.w}, dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + (lane >> 4) * 4 + r;
-                    const float p = (qi < T && key < T) ? expf(st[r] * scale - lq) : 0.f;
-                    const float val = sweep == 0 ? p : p * (dpt[r] - dq_i) * scale;
-                    myP[((lane >> 4) * 4 + r) * ATT_PK + qi] = f32_to_bf16_bits(val);
+                    const float p = (key_ok && q0 + r < T) ? __builtin_amdgcn_exp2f((st[r] * scale - lqv[r]) * 1.44269504088896f) : 0.f;
+                    v[r] = sweep == 0 ? p : p * (dpt[r] - dqv[r]) * scale;
                 }
+                *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_PK + q0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
 #pragma unroll
             for (int kk = 0; kk < ATT_PK / 32; ++kk) {
