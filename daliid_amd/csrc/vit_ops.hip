@@ -314,50 +314,38 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const uint16_t* __re
     for (int qt = wave; qt < ATT_TP / 16; qt += 4) {
         if (qt * 16 >= T) break;
         const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
+        // Score tiles are computed TRANSPOSED (rows = keys, columns = this tile's 16 queries): a lane owns ONE query (lane&15)
+        // and 4 consecutive keys per tile, so the softmax statistics are one value per lane, the cross-lane part is two
+        // shuffles over the 4 lane groups, and P goes to the [query][key] strip with 8-byte writes.
         f32x4_t s[ATT_TP / 16];
+        const float sc2 = scale * 1.44269504088896f;                 // exp(x) = 2^(x log2 e)
+        float m = -__builtin_inff();
 #pragma unroll
         for (int j = 0; j < ATT_TP / 16; ++j) {
             f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag_k(sK, ATT_LD, j * 16, 0, lane), a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag_k(sK, ATT_LD, j * 16, 32, lane), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, a, 0, 0, 0);
+            const int key0 = j * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (key0 + r < T) ? a[r] * sc2 : -__builtin_inff(); m = fmaxf(m, a[r]); }
             s[j] = a;
         }
-        // row softmax: element (j, r) is row (lane>>4)*4 + r, key j*16 + (lane&15)
-        float m[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-#pragma unroll
-        for (int j = 0; j < ATT_TP / 16; ++j) {
-            const bool valid = j * 16 + (lane & 15) < T;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[j][r] = valid ? s[j][r] * scale : -__builtin_inff(); m[r] = fmaxf(m[r], s[j][r]); }
-        }
-        float l[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], o, 64));
-            l[r] = 0.f;
-        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
 #pragma unroll
         for (int j = 0; j < ATT_TP / 16; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[j][r] = expf(s[j][r] - m[r]); l[r] += s[j][r]; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) l[r] += __shfl_xor(l[r], o, 64);
-        }
-        // P -> per-wave LDS strip [16][224] bf16
+            for (int r = 0; r < 4; ++r) { s[j][r] = __builtin_amdgcn_exp2f(s[j][r] - m); l += s[j][r]; }
+        l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+        const float inv_l = 1.0f / l;
+        // P -> per-wave LDS strip [16 queries][224 keys] bf16
 #pragma unroll
         for (int j = 0; j < ATT_TP / 16; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                myP[((lane >> 4) * 4 + r) * ATT_PK + j * 16 + (lane & 15)] = f32_to_bf16_bits(s[j][r] / l[r]);
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = qt * 16 + (lane >> 4) * 4 + r;
-                if (row < T && lse) lse[(size_t)bh * T + row] = m[r] + logf(l[r]);
-            }
+            *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_PK + j * 16 + (lane >> 4) * 4) =
+                make_uint2(pack_bf16x2(s[j][0] * inv_l, s[j][1] * inv_l), pack_bf16x2(s[j][2] * inv_l, s[j][3] * inv_l));
+        if (lane < 16) {
+            const int row = qt * 16 + lane;
+            if (row < T && lse) lse[(size_t)bh * T + row] = (m + log2f(l)) * 0.6931471805599453f;     // natural-log lse = max + log(sum)
         }
         // O = P V : A = P (k = key, contiguous), B[k = key][n = d] = V[key][d] through the transposing read
         f32x4_t o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
