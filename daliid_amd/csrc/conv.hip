@@ -350,6 +350,8 @@ __device__ __forceinline__ void dma_wait() {
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else static_assert(N == 0, "unsupported DMA count");
 }
 
@@ -852,6 +854,179 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient with halo reuse.  In the GEMM view above every 128-column group of N is one
+// tap's gather, so a block re-loads the same dY pixels and the (shifted) same X pixels for each of the 9 taps: 18 operand
+// tiles per (co tile, ci tile, 32 pixels).  Here one 8-wave block owns 128 output channels x 64 input channels x ALL 9
+// taps: per k-step (32 consecutive pixels = 32/W full image rows) it fetches the dY tile [32 px][128 co] and ONE halo patch
+// of X, (32/W + 2) x (W + 2) pixels x 64 ci, and every tap's B operand is the same LDS patch read at a shifted row
+// (halo row (hh + r) * (W + 2) + col + s): 2 operand tiles instead of 18, 4.7 x fewer L2 -> LDS bytes per FLOP.
+// Wave (wm, wn) of the 2 x 4 grid owns 64 co x 16 ci x 9 taps (144 accumulator registers).  The halo patch is pixel-major
+// [px][64 ci] (128-byte rows, what an LDS-DMA block of 8 pixels writes) with the 32-byte chunk index XORed with
+// halo_swz(px) so that the 2 x 4 rows one LDS cycle of a transposing read touches fall into different banks at any shift.
+// Needs W in {8, 16, 32}, H*W a power of two >= 32, Cout % 64 == 0, Cin % 64 == 0.  Split-K over pixels as before.
+// ------------------------------------------------------------------------------------------------
+// XOR on the 32-byte chunk index (4 per 128-byte halo row): a transposing read serves 32 lanes per LDS cycle = 2 lane groups x
+// 4 consecutive rows, the groups 8 rows apart: (row & 1) picks the 128-byte half of the 64 banks, this picks the quarter
+__device__ __forceinline__ int halo_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+constexpr int W3_A_ELEMS = 32 * 128, W3_B_ELEMS = 16 * 512, W3_STAGE = W3_A_ELEMS + W3_B_ELEMS;      // 8 KiB + 16 KiB
+
+template <int NSTAGE>
+__global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles = tiles_m * tiles_n;
+    const int work = tiles * a.splits, per_xcd = (work + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= work) return;
+    const int ks = item / tiles, tile = item - ks * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 128, ci0 = tn * 64;
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
+    const bool m_active = m0 + wm * 64 < a.Cm;          // Cout = 64: the upper half of the co tile is padding, its waves only help with the DMA
+    const GatherGeom g = a.g;
+    const int W = g.Wout, H = g.Hout, Cin = g.Ck, lw = g.lw, lhw = g.lhw;
+    const int RW = 32 >> lw, HC = W + 2, HP = (RW + 2) * HC;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * (a.P >> lhw);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+
+    // dY DMA (block = wave): row 4*wave + lane>>4 of the [32][128] image, swizzled 16-byte slot as in igemm_wgrad_dma_kernel
+    const int r_in = lane >> 4, ps = lane & 15;
+    const int c16 = ((((ps >> 1) ^ wg_swz(4 * wave + r_in)) << 1) | (ps & 1));
+    const int am = m0 + c16 * 8;
+    const bool a_ok = am < a.Cm;
+    // halo DMA (blocks wave and wave + 8): halo pixel 8*blk + lane>>3, physical 16-byte chunk lane&7
+    int hb_hr[2], hb_off[2];
+    bool hb_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hp = 8 * (wave + 8 * i) + (lane >> 3);
+        const int lc = (lane & 7) ^ (halo_swz(hp) << 1);                  // logical 16-byte chunk stored in this physical slot
+        const int hr = hp / HC, hc = hp - hr * HC;
+        hb_hr[i] = hr;
+        hb_ok[i] = hp < HP && (unsigned)(hc - 1) < (unsigned)W && ci0 + lc * 8 < Cin;
+        hb_off[i] = ((hc - 1) * Cin + ci0 + lc * 8) * 2;                   // bytes inside an image row (+ row / image part per k-step)
+    }
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.P, p_begin + a.pix_per_split);
+    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+
+    auto issue = [&](int kt, int stage) {
+        uint16_t* sa = smem + stage * W3_STAGE;
+        uint16_t* sb = sa + W3_A_ELEMS;
+        const int p0 = p_begin + kt * 32;
+        const int p = p0 + 4 * wave + r_in;
+        const uint32_t oa = (p < p_end && a_ok) ? (uint32_t)(p * a.Cm + am) * 2u : DMA_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)(sa + wave * 512), 16, oa, 0, 0, 0);
+        const int n = p0 >> lhw, h_base = (p0 & ((1 << lhw) - 1)) >> lw;       // wave-uniform: first image row of this k-step
+        const int row_bytes = W * Cin * 2;
+        const int img_base = (int)((long long)n * g.img_pitch * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int h = h_base - 1 + hb_hr[i];
+            const bool ok = hb_ok[i] && (unsigned)h < (unsigned)H && p0 < p_end;
+            const uint32_t ob = ok ? (uint32_t)(img_base + h * row_bytes + hb_off[i]) : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + 8 * i) * 512), 16, ob, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // transposing read of the halo patch: lane group gq = lane>>4 covers pixels 8*gq .. 8*gq+7 of the k-step
+    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int hrow_base = ((8 * gq) >> lw) * HC + ((8 * gq) & (W - 1)) + q;    // halo row of (tap 0,0), first of the two reads
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    // the 9 taps' read offsets inside the patch do not depend on the k-step: computed once
+    int boff0[9], boff1[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int row0 = hrow_base + r * HC + s2, row1 = row0 + 4;
+            boff0[r * 3 + s2] = row0 * 64 + ((wn ^ halo_swz(row0)) << 4) + 4 * pp;
+            boff1[r * 3 + s2] = row1 * 64 + ((wn ^ halo_swz(row1)) << 4) + 4 * pp;
+        }
+    auto load_b = [&](const uint16_t* sb, int t) -> bf16x8_t {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(sb + boff0[t]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(sb + boff1[t]));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
+    };
+
+    // NSTAGE-deep ring, NSTAGE-1 k-steps in flight: with one 8-wave block per CU the bytes in flight are what hides the
+    // ~2 us load latency (3 stages: 1.25 us per k-step, load-latency-bound; the MFMA work is 0.5 us)
+    constexpr int AHEAD = NSTAGE - 1;
+    auto wait_inflight = [&](int n) {                  // n = k-steps that may stay in flight (each = 3 DMA pieces per wave)
+        if (n <= 0) dma_wait<0>();
+        else if (n == 1) dma_wait<3>();
+        else if (n == 2) dma_wait<6>();
+        else if (n == 3) dma_wait<9>();
+        else dma_wait<12>();
+    };
+    static_assert(AHEAD >= 1 && AHEAD <= 5, "ring depth");
+    if (ksteps > 0) {
+        int issued = 0;
+        for (; issued < AHEAD && issued < ksteps; ++issued) issue(issued, issued);
+        wait_inflight(issued - 1 > 4 ? 4 : issued - 1);
+        __builtin_amdgcn_s_barrier();
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
+        int st_cur = 0, st_fill = AHEAD % NSTAGE;
+        for (int kt = 0; kt < ksteps; ++kt) {
+            if (kt + AHEAD < ksteps) issue(kt + AHEAD, st_fill);
+            const uint16_t* sa = smem + st_cur * W3_STAGE;
+            const uint16_t* sb = sa + W3_A_ELEMS;
+            if (m_active) {
+            bf16x8_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, wm * 4 + i, lane);
+            // all nine taps' fragments are requested up front (36 VGPRs): one exposed LDS latency per k-step instead of nine
+            // (the compiler otherwise sinks every read to just before its MFMAs, with a full lgkmcnt wait each time)
+            bf16x8_t fb[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) fb[t] = load_b(sb, t);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[t], acc[t][i], 0, 0, 0);
+            }
+            // k-step kt+1 must have landed: everything but the youngest min(AHEAD - 1, remaining - 1) k-steps
+            const int left = ksteps - 1 - kt;
+            const int keep = (left < AHEAD ? left : AHEAD) - 1;
+            wait_inflight(keep > 4 ? 4 : keep);
+            __builtin_amdgcn_s_barrier();
+            st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
+            st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
+        }
+    }
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
+    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
+    if (m_active)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int n = t * Cin + ci0 + wn * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
+                slab[(size_t)m * a.Ntot + n] = acc[t][i][rr];
+            }
+    }
+    if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
+    }
+}
+
 // wgrad, wave-grid variant: WM x WN waves of 64 x 64 sub-tiles; the (64*WM) x (64*WN) block tile is held as (TM+TN)/128
 // swizzled [32 px][128 ch] LDS images per stage (same image / tr-read scheme as above), NSTAGE-deep ring.
 template <int WM, int WN, int NSTAGE>
@@ -1198,20 +1373,22 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
 // 1 = 256 x 256 / 16 waves, 2 = 128 x 256 / 8 waves.  The wider tiles cut the L2 -> LDS operand bytes per FLOP and win
 // on the 1x1 layers with a long pixel (K) dimension; on 3x3 layers (each 128-column group of N is one tap's gather)
 // and on the ViT linears (25 k rows: the split-K slabs double) they lose.
-int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P) {
+int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P, int halo_w) {
     static int ov = -2;
     if (ov == -2) { const char* e = getenv("DALI_WGRAD_CFG"); ov = e ? atoi(e) : -1; }
+    // 3 = 3x3 halo kernel (128 co x 64 ci x 9 taps per block)
+    if (ov != 0 && taps == 9 && (halo_w == 8 || halo_w == 16 || halo_w == 32) && Cm % 64 == 0 && (Ntot / 9) % 64 == 0 && P % 32 == 0) return 3;
     if (ov == 2) return (Ntot >= 256) ? 2 : 0;
     if (ov >= 0) return (ov == 1 && Cm >= 256 && Ntot >= 256) ? 1 : 0;
     return (taps == 1 && Ntot >= 256 && P >= 32768) ? 2 : 0;
 }
-void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps) {
+void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps, int halo_w) {
     static int target_override = -2;
     if (target_override == -2) { const char* e = getenv("DALI_WGRAD_TARGET"); target_override = e ? atoi(e) : -1; }
     if (target_override > 0) target_blocks = target_override;
-    const int cfg = wgrad_pick_cfg(Cm, Ntot, taps, P);
-    const int TMc = cfg == 1 ? 256 : 128, TNc = cfg == 0 ? 128 : 256;
-    if (cfg == 1) target_blocks = 256;              // one 16-wave block per CU
+    const int cfg = wgrad_pick_cfg(Cm, Ntot, taps, P, halo_w);
+    const int TMc = cfg == 1 ? 256 : 128, TNc = cfg == 0 ? 128 : (cfg == 3 ? 9 * 64 : 256);
+    if (cfg == 1 || cfg == 3) target_blocks = 256;  // one 16-wave / 8-wave block per CU
     if (cfg == 2) target_blocks = 512;              // two 8-wave blocks per CU
     const int tiles = ((Cm + TMc - 1) / TMc) * ((Ntot + TNc - 1) / TNc);
     int sp = (target_blocks + tiles - 1) / tiles;
@@ -1235,8 +1412,16 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const bool dma_ok = x_bytes < 0x7ff00000ll && (long long)a.P * a.Cm * 2 < 0x7ff00000ll;
     {
     ProfScope prof_scope(st, 1, 2.0 * a.Cm * (double)a.Ntot * a.P);
-    const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P);
-    if (!a.in_scale && dma_ok && wcfg == 1) {
+    const bool halo_ok = a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && a.g.mode == 0 && args.g.lw >= 0 && args.g.lhw >= 0 &&
+                         a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck;
+    const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P, halo_ok ? a.g.Wout : 0);
+    if (!a.in_scale && dma_ok && wcfg == 3) {
+        static bool attr_set = false;
+        const int tm3 = (a.Cm + 127) / 128, tn3 = a.g.Ck / 64;
+        const int lds = 3 * W3_STAGE * 2;            // 3 stages x 24 KiB (deeper rings measured the same: the loop is issue-bound)
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL(igemm_wgrad3x3_kernel<3>, dim3(((tm3 * tn3 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm3, tn3);
+    } else if (!a.in_scale && dma_ok && wcfg == 1) {
         static bool attr_set = false;
         const int tm2 = (a.Cm + 255) / 256, tn2 = (a.Ntot + 255) / 256;
         const int lds = 4 * 4 * 32 * 128 * 2;       // 4 stages x 4 images x 8 KiB
@@ -1356,7 +1541,8 @@ extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
     a.Cm = cout; a.P = n * ho * wo; a.Ntot = r * s * cin;
     fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
     size_t ws_bytes;
-    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &ws_bytes, r * s);
+    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &ws_bytes, r * s,
+               (r == 3 && s == 3 && stride == 1 && pad == 1 && in_scale == nullptr && ilog2_exact(wo) >= 0 && ilog2_exact(ho * wo) >= 0) ? wo : 0);
     a.partial = static_cast<float*>(workspace(ctx, ws_bytes));
     if (!a.partial) return DALI_ERR_NOMEM;
     return launch_igemm_wgrad((hipStream_t)stream, a, dw, accumulate);

@@ -59,7 +59,8 @@ struct BnBwdSide { const uint16_t* raw; const float* mean; const float* invstd; 
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a);
 int igemm_conv_stat_tiles(int Cm, int P, int K);
 // taps = R*S of the convolution (1 for 1x1 convolutions and linear layers): selects the tile shape
-void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps = 1);
+// halo_w = output width of a 3x3 / stride 1 / pad 1 convolution whose H*W is a power of two (0 otherwise): enables the halo kernel
+void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps = 1, int halo_w = 0);
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
 
 int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,

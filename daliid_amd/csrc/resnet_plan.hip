@@ -122,6 +122,11 @@ void reserve_bn(dali_resnet* net, Arena& a, Bn& b) {
     reserve(net, a, b.coef, b.C * 12);
 }
 
+// output width if conv c is a 3x3 / stride 1 / pad 1 convolution on a power-of-two pixel grid (the halo wgrad kernel), else 0
+int conv_halo_w(const Conv& c) {
+    const bool pow2 = (c.wout & (c.wout - 1)) == 0 && ((c.hout * c.wout) & (c.hout * c.wout - 1)) == 0;
+    return (c.r == 3 && c.s == 3 && c.stride == 1 && c.pad == 1 && pow2) ? c.wout : 0;
+}
 GatherGeom conv_geom(const Conv& c, int mode) {
     GatherGeom g{};
     if (mode == 0) {
@@ -233,7 +238,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             const int P = (int)N * c->hout * c->wout;
             max_stat = std::max(max_stat, (size_t)igemm_conv_stat_tiles(c->cout, P, c->r * c->s * c->cin) * c->cout * 2 * 4);
             int sp, pps; size_t wsb;
-            wgrad_plan(c->cout, c->r * c->s * c->cin, P, 512, &sp, &pps, &wsb, c->r * c->s);
+            wgrad_plan(c->cout, c->r * c->s * c->cin, P, 512, &sp, &pps, &wsb, c->r * c->s, conv_halo_w(*c));
             max_slab = std::max(max_slab, wsb);
             max_act = std::max(max_act, (size_t)P * c->cout * 2);
             max_act = std::max(max_act, N * c->hin * c->win * c->cin * 2);
@@ -357,7 +362,7 @@ int conv_wgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* 
     a.Cm = c.cout; a.P = net->N * c.hout * c.wout; a.Ntot = c.r * c.s * c.cin;
     a.g = conv_geom(c, 0);
     size_t wsb;
-    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb, c.r * c.s);
+    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb, c.r * c.s, in_bn ? 0 : conv_halo_w(c));
     return launch_igemm_wgrad(st, a, net->G + c.w_off, 0);
 }
 

@@ -24,6 +24,9 @@ CASES = [
     (2, 32, 16, 128, 128, 3, 3, 2, 1),    # layer2 conv2 (stride 2): dgrad split by output parity, 4 sub-problems
     (3, 6, 10, 32, 64, 3, 3, 2, 1),       # stride 2 on a grid whose halves are not powers of two: un-split dgrad
     (2, 16, 8, 256, 512, 1, 1, 2, 0),     # layer2 downsample: in-place dgrad touches the even-even quarter only
+    (2, 16, 8, 64, 64, 3, 3, 1, 1),       # layer1 conv2: halo wgrad kernel with a half-empty 128-channel co tile
+    (3, 32, 32, 64, 128, 3, 3, 1, 1),     # halo wgrad, W = 32 (one image row per k-step), 3 images
+    (2, 8, 16, 128, 192, 3, 3, 1, 1),     # halo wgrad, W = 16, Cout = 192 (1.5 co tiles)
 ]
 
 
