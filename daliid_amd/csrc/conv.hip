@@ -1412,7 +1412,7 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const bool dma_ok = x_bytes < 0x7ff00000ll && (long long)a.P * a.Cm * 2 < 0x7ff00000ll;
     {
     ProfScope prof_scope(st, 1, 2.0 * a.Cm * (double)a.Ntot * a.P);
-    const bool halo_ok = a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && a.g.mode == 0 && args.g.lw >= 0 && args.g.lhw >= 0 &&
+    const bool halo_ok = a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && a.g.mode == 0 && args.g.lw >= 0 && args.g.lhw >= 7 &&
                          a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck;
     const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P, halo_ok ? a.g.Wout : 0);
     if (!a.in_scale && dma_ok && wcfg == 3) {
@@ -1508,9 +1508,14 @@ extern "C" int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, c
     return launch_igemm_conv((hipStream_t)stream, a);
 }
 
-extern "C" int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int n, int ho, int wo, int fused_operand) {
+// output width if the geometry is what the 3x3 halo kernels take (3x3, stride 1, pad 1, power-of-two pixel grid), else 0
+static int halo_width(int r, int s, int stride, int pad, int ho, int wo) {
+    return (r == 3 && s == 3 && stride == 1 && pad == 1 && ilog2_exact(wo) >= 0 && ilog2_exact(ho * wo) >= 0 && ho * wo >= 128) ? wo : 0;
+}
+extern "C" int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int stride, int pad, int n, int ho, int wo, int fused_operand) {
     // the fused-operand (register-staged) kernels always use 128-pixel tiles for cout > 64
     if (fused_operand && cout > 64) return (n * ho * wo + 127) / 128;
+    (void)stride; (void)pad;
     return igemm_conv_stat_tiles(cout, n * ho * wo, r * s * cin);
 }
 
@@ -1542,7 +1547,7 @@ extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
     fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
     size_t ws_bytes;
     wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &ws_bytes, r * s,
-               (r == 3 && s == 3 && stride == 1 && pad == 1 && in_scale == nullptr && ilog2_exact(wo) >= 0 && ilog2_exact(ho * wo) >= 0) ? wo : 0);
+               in_scale == nullptr ? halo_width(r, s, stride, pad, ho, wo) : 0);
     a.partial = static_cast<float*>(workspace(ctx, ws_bytes));
     if (!a.partial) return DALI_ERR_NOMEM;
     return launch_igemm_wgrad((hipStream_t)stream, a, dw, accumulate);

@@ -125,7 +125,7 @@ void reserve_bn(dali_resnet* net, Arena& a, Bn& b) {
 // output width if conv c is a 3x3 / stride 1 / pad 1 convolution on a power-of-two pixel grid (the halo wgrad kernel), else 0
 int conv_halo_w(const Conv& c) {
     const bool pow2 = (c.wout & (c.wout - 1)) == 0 && ((c.hout * c.wout) & (c.hout * c.wout - 1)) == 0;
-    return (c.r == 3 && c.s == 3 && c.stride == 1 && c.pad == 1 && pow2) ? c.wout : 0;
+    return (c.r == 3 && c.s == 3 && c.stride == 1 && c.pad == 1 && pow2 && c.hout * c.wout >= 128) ? c.wout : 0;
 }
 GatherGeom conv_geom(const Conv& c, int mode) {
     GatherGeom g{};

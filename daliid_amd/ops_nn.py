@@ -20,7 +20,7 @@ def conv2d_fwd(x, w, stride=1, pad=0, in_scale=None, in_shift=None, in_relu=Fals
     y = torch.empty(n, ho, wo, cout, device=x.device, dtype=bf16)
     stats = None
     if want_stats:
-        tiles = _lib.lib().dali_conv2d_stat_tiles(cout, cin, r, s, n, ho, wo, int(in_scale is not None))
+        tiles = _lib.lib().dali_conv2d_stat_tiles(cout, cin, r, s, stride, pad, n, ho, wo, int(in_scale is not None))
         stats = torch.empty(tiles, cout, 2, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().dali_conv2d_fwd(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16, "x"), _lib.ptr(w, bf16, "w"),
                                            _lib.ptr(y), n, h, wd, cin, cout, r, s, stride, pad,

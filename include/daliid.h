@@ -119,7 +119,7 @@ int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16
                     int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
                     const float* in_scale, const float* in_shift, int in_relu, float* stats);
 /* rows of the `stats` buffer for a given problem (depends on the tile configuration the launcher will pick). */
-int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int n, int ho, int wo, int fused_operand);
+int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int stride, int pad, int n, int ho, int wo, int fused_operand);
 /* dx[n,h,w,cin] = conv_transpose(dy, w) (+ residual[n,h,w,cin] if given).  cout % 32 == 0, cin % 4 == 0. */
 int dali_conv2d_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, uint16_t* dx,
                       const uint16_t* residual, int n, int h, int wd, int cin, int cout, int r, int s,
