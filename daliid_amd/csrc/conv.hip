@@ -1217,7 +1217,7 @@ namespace dali {
 
 // Tile configuration per problem (measured on MI355X, scripts/bench_convs.py): 64x256 for <= 64 output channels;
 // 256x256 / 16 waves / 4-deep ring when both K and Cm are large (operand traffic per FLOP halves: +25..36 % on the
-// layer4 3x3); 128x256 / 8 waves for Cm = 256 with K >= 1024; 128x128 / 4 waves otherwise (small K: prologue-bound).
+// layer4 3x3); 128x256 / 8 waves for Cm = 128..256 with K >= 1024; 128x128 / 4 waves otherwise (small K: prologue-bound).
 enum ConvCfg { CONV_NARROW = 0, CONV_128 = 1, CONV_128x256 = 2, CONV_256x256 = 3, CONV_256x128 = 4 };
 static int conv_cfg_override() {
     static int v = -2;
@@ -1231,9 +1231,10 @@ int conv_pick_cfg(int Cm, int P, int K) {
     if (ov == 4) return Cm >= 256 ? CONV_256x256 : CONV_128;
     if (ov == 6) return Cm >= 256 ? CONV_128x256 : CONV_128;
     if (ov == 7) return Cm >= 256 ? CONV_256x128 : CONV_128;
+    if (ov == 9) return Cm >= 128 ? CONV_128x256 : CONV_128;
     if (K >= 1024 && P >= 16384) {
         if (Cm >= 512) return CONV_256x256;
-        if (Cm >= 256) return CONV_128x256;
+        if (Cm >= 128) return CONV_128x256;             // Cm = 128 (layer2 3x3): -18 % against 128 x 128
     }
     return CONV_128;
 }
