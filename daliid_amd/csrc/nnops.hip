@@ -51,21 +51,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            float momentum, float eps, float* __restrict__ scale,
                                                            float* __restrict__ shift, float* __restrict__ mean_out,
                                                            float* __restrict__ invstd_out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) {
-        double a = 0.0, b = 0.0;
-        int t = 0;
-        for (; t + 8 <= tiles; t += 8) {                  // 8 loads in flight (tiles goes up to REDUCE_SMAX = 64)
-            double2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(partial + ((size_t)(t + u) * C + c) * 2);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
-        }
-        for (; t < tiles; ++t) {
+    // block = 32 channels x 8 row slices (a single thread walking up to 64 rows was latency-bound: 5-7 us per launch);
+    // slice sums are added in a fixed order
+    __shared__ double red[2][8][32];
+    const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int t = sl; t < tiles; t += 8) {
             const double2 v = *reinterpret_cast<const double2*>(partial + ((size_t)t * C + c) * 2);
             a += v.x; b += v.y;
         }
+    red[0][sl][cx] = a; red[1][sl][cx] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        a = 0.0; b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
         const double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -213,18 +215,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                float* __restrict__ coef, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) {
-        double a = 0.0, b = 0.0;
-        int t = 0;
-        for (; t + 8 <= blocks; t += 8) {                 // 8 x 2 loads in flight
-            double va[8], vb[8];
+    __shared__ double red[2][8][32];                       // 32 channels x 8 row slices per block, fixed-order slice sums
+    const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int t = sl; t < blocks; t += 8) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
+    red[0][sl][cx] = a; red[1][sl][cx] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        a = 0.0; b = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const double* p = partial + ((size_t)(t + u) * C + c) * NV; va[u] = p[0]; vb[u] = p[which]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
-        }
-        for (; t < blocks; ++t) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
+        for (int k = 0; k < 8; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
         const double sc = (double)scale[c];
         const double q = sc * (double)invstd[c] * (b / count);
         coef[c] = scale[c];
@@ -633,7 +635,7 @@ int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, d
                        double* scratch) {
     int S, rc;
     if ((rc = reduce_partials(st, partial, tiles, C * 2, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, count, gamma, beta, rm, rv, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, count, gamma, beta, rm, rv, momentum,
                        eps, scale, shift, mean, invstd);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
@@ -681,11 +683,11 @@ int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, cons
     DALI_LAUNCH_CHECK();
     int S, rc;
     if ((rc = reduce_partials(st, partial, blocks, C * NV, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 1, (double)P, a.scale, a.mean, a.invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, NV, 1, (double)P, a.scale, a.mean, a.invstd,
                        coef_a, dgamma_a, dbeta_a);
     DALI_LAUNCH_CHECK();
     if (dual) {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, NV, 2, (double)P, bb.scale, bb.mean, bb.invstd,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, NV, 2, (double)P, bb.scale, bb.mean, bb.invstd,
                            coef_b, dgamma_b, dbeta_b);
         DALI_LAUNCH_CHECK();
     }
@@ -736,7 +738,7 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     DALI_LAUNCH_CHECK();
     int S, rc;
     if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 1, (double)P, scale, mean, invstd, coef,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, 2, 1, (double)P, scale, mean, invstd, coef,
                        dgamma, dbeta);
     DALI_LAUNCH_CHECK();
     hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 8))), dim3(256), 0, st, dp, arg, raw, mean, invstd, coef, N, H,
