@@ -87,7 +87,7 @@ def bench_distance(args, world, rank):
     k_ms = ev[0].elapsed_time(ev[1]) / args.steps
     flops = 2.0 * d * nq * ng
     achieved = flops / (k_ms * 1e-3) / 1e12
-    roofline = {"kernel": "pairdist_kernel<%d>" % (3 if prec == "bf16x3" else 1), "bound": "mfma",
+    roofline = {"kernel": "pairdist_dma_kernel<%d>" % (3 if prec == "bf16x3" else 1), "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                 "kernel_ms": round(k_ms, 4), "mfma_issue_multiplier": 3 if prec == "bf16x3" else 1}

@@ -336,24 +336,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
 // each lane fetches.  Two LDS stages, one barrier per k-tile: the DMA of tile t+1 is in flight while tile t is
 // multiplied.  Tap / channel position advance as wave-uniform scalars (no per-load division).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-constexpr uint32_t DMA_OOB = 0x7ffffff0u;
-
-// wait until at most N of this wave's vector-memory operations (the LDS-DMA loads) are still in flight; also drains
-// this wave's LDS reads so the following barrier orders them against the next refill
-template <int N>
-__device__ __forceinline__ void dma_wait() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-    else static_assert(N == 0, "unsupported DMA count");
-}
+// (lds_void_ptr, DMA_OOB, dma_wait<N> live in gemm_tile.h: shared with eval.hip)
 
 template <int TM, int TN, int NSTAGE>
 __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {

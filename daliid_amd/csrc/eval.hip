@@ -2,6 +2,7 @@
 //   row L2 normalisation (:41-42), distmat = 1 - q @ g.T (:47) on MFMA, and the market1501 CMC/mAP
 //   arithmetic of torchreid.metrics.evaluate_rank (:68) without a full row sort.
 #include "gemm_tile.h"
+#include <cstdlib>
 
 namespace dali {
 
@@ -107,36 +108,20 @@ struct PairBlend {
     int on;
 };
 
-template <int NPROD>
-__global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restrict__ Ghi, const uint16_t* __restrict__ Glo,
-                                                       const uint16_t* __restrict__ Qhi, const uint16_t* __restrict__ Qlo,
-                                                       const float* __restrict__ gsq, const float* __restrict__ qsq,
-                                                       int ng, int nq, int Kp, int metric, float* out,
-                                                       int tiles_m, int tiles_n, PairBlend blend) {
-    using Cfg = typename PairCfg<NPROD>::type;
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    int tm, tn;
-    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
-    f32x4_t acc[Cfg::FM][Cfg::FN];
-#pragma unroll
-    for (int i = 0; i < Cfg::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < Cfg::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    RowLoader la{Ghi, Glo, tm * Cfg::TM, ng, Kp};
-    RowLoader lb{Qhi, Qlo, tn * Cfg::TN, nq, Kp};
-    gemm_mainloop<Cfg>(acc, la, lb, Kp / 32, smem);
-
-    int mb, nb;
-    acc_coords<Cfg>(mb, nb);
+// Epilogue shared by the distance kernels: metric, optional two-model blend, fp32 store (4 consecutive gallery entries per lane).
+// mb / nb: this lane's first gallery row / query column inside the tile (accumulator layout: rows (lane>>4)*4 + r, column lane&15).
+template <int FM, int FN>
+__device__ __forceinline__ void pairdist_epilogue(f32x4_t (&acc)[FM][FN], int g_tile0, int q_tile0, int mb, int nb, const float* __restrict__ gsq,
+                                                  const float* __restrict__ qsq, int ng, int nq, int metric, float* out, const PairBlend& blend) {
     const bool vec_ok = (ng & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < Cfg::FN; ++j) {
-        const int q = tn * Cfg::TN + nb + j * 16;
+    for (int j = 0; j < FN; ++j) {
+        const int q = q_tile0 + nb + j * 16;
         if (q >= nq) continue;
         const float qq = (metric == DALI_METRIC_L2SQ) ? qsq[q] : 0.f;
 #pragma unroll
-        for (int i = 0; i < Cfg::FM; ++i) {
-            const int g0 = tm * Cfg::TM + mb + i * 16;
+        for (int i = 0; i < FM; ++i) {
+            const int g0 = g_tile0 + mb + i * 16;
             if (g0 >= ng) continue;
             float v[4];
 #pragma unroll
@@ -179,6 +164,130 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
             }
         }
     }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restrict__ Ghi, const uint16_t* __restrict__ Glo,
+                                                       const uint16_t* __restrict__ Qhi, const uint16_t* __restrict__ Qlo,
+                                                       const float* __restrict__ gsq, const float* __restrict__ qsq,
+                                                       int ng, int nq, int Kp, int metric, float* out,
+                                                       int tiles_m, int tiles_n, PairBlend blend) {
+    using Cfg = typename PairCfg<NPROD>::type;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    f32x4_t acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    RowLoader la{Ghi, Glo, tm * Cfg::TM, ng, Kp};
+    RowLoader lb{Qhi, Qlo, tn * Cfg::TN, nq, Kp};
+    gemm_mainloop<Cfg>(acc, la, lb, Kp / 32, smem);
+
+    int mb, nb;
+    acc_coords<Cfg>(mb, nb);
+    pairdist_epilogue<Cfg::FM, Cfg::FN>(acc, tm * Cfg::TM, tn * Cfg::TN, mb, nb, gsq, qsq, ng, nq, metric, out, blend);
+}
+
+// LDS-DMA version (what the launcher uses when the operands fit 32-bit buffer offsets): 128 gallery rows x 256 query
+// rows per 8-wave block (wave (wm, wn) of the 2 x 4 grid owns 64 x 64), every operand image [rows][32] travels HBM/L2 -> LDS
+// with buffer_load_dwordx4 ... lds (no VGPR staging), 3-stage ring with counted vmcnt.  NPROD = 3: hi and lo images of both
+// sides (48 KiB per stage); per k-step a wave reads 16 fragments for 48 MFMAs -- three times the MFMA work per DMA piece of
+// the convolution kernels, which are issue-bound.
+template <int NPROD>
+__global__ __launch_bounds__(512) void pairdist_dma_kernel(const uint16_t* __restrict__ Ghi, const uint16_t* __restrict__ Glo,
+                                                           const uint16_t* __restrict__ Qhi, const uint16_t* __restrict__ Qlo,
+                                                           const float* __restrict__ gsq, const float* __restrict__ qsq,
+                                                           int ng, int nq, int Kp, int metric, float* out,
+                                                           int tiles_m, int tiles_n, PairBlend blend) {
+    constexpr int TM = 128, TN = 256, NARR = NPROD == 3 ? 2 : 1;
+    constexpr int A_ELEMS = TM * 32, B_ELEMS = TN * 32, STAGE = NARR * (A_ELEMS + B_ELEMS);
+    constexpr int NBLK = NARR * (TM + TN) / 16, NDMA = NBLK / 8;                 // 1 KiB DMA blocks per stage / per wave
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ktiles = Kp >> 5;
+    const __amdgpu_buffer_rsrc_t rs[4] = {
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ghi), 0, ng * Kp * 2, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Glo), 0, ng * Kp * 2, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Qhi), 0, nq * Kp * 2, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Qlo), 0, nq * Kp * 2, 0x00020000)};
+    // this wave's DMA blocks: q = wave + 8*i; LDS order inside a stage: [A hi][A lo][B hi][B lo] (lo only for NPROD = 3)
+    const int r_in = lane >> 2;
+    const int kc = (lane & 3) ^ lds_swz(r_in);
+    uint32_t off[NDMA];
+    int arr[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int q = wave + 8 * i;
+        const int a_blocks = NARR * (TM / 16);
+        const bool is_a = q < a_blocks;
+        const int qa = is_a ? q : q - a_blocks;
+        const int rows16 = is_a ? TM / 16 : TN / 16;
+        const int which = qa / rows16, blk = qa - which * rows16;                // which: 0 hi, 1 lo
+        const int row = (is_a ? tm * TM : tn * TN) + blk * 16 + r_in;
+        arr[i] = (is_a ? 0 : 2) + which;
+        off[i] = (row < (is_a ? ng : nq)) ? (uint32_t)(row * Kp + kc * 8) * 2u : DMA_OOB;
+    }
+    auto issue = [&](int kt, int stage) {
+        uint16_t* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const uint32_t o = (off[i] == DMA_OOB) ? DMA_OOB : off[i] + (uint32_t)(kt * 64);
+            uint16_t* dst = base + (wave + 8 * i) * 512;
+            if (arr[i] == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[0], (lds_void_ptr)dst, 16, o, 0, 0, 0);
+            else if (arr[i] == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[1], (lds_void_ptr)dst, 16, o, 0, 0, 0);
+            else if (arr[i] == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[2], (lds_void_ptr)dst, 16, o, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[3], (lds_void_ptr)dst, 16, o, 0, 0, 0);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frag_off = (lane & 15) * 32 + (((lane >> 4) ^ lds_swz(lane & 15)) << 3);
+    issue(0, 0);
+    if (ktiles > 1) issue(1, 1);
+    if (ktiles > 1) dma_wait<NDMA>(); else dma_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    int st_cur = 0, st_fill = 2;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        if (kt + 2 < ktiles) issue(kt + 2, st_fill);
+        const uint16_t* sa_hi = smem + st_cur * STAGE;
+        const uint16_t* sa_lo = sa_hi + A_ELEMS;                                 // valid for NPROD = 3 only
+        const uint16_t* sb_hi = sa_hi + NARR * A_ELEMS;
+        const uint16_t* sb_lo = sb_hi + B_ELEMS;
+        bf16x8_t ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const bf16x8_t*>(sa_hi + (wm * 64 + i * 16) * 32 + frag_off);
+            if (NPROD == 3) al[i] = *reinterpret_cast<const bf16x8_t*>(sa_lo + (wm * 64 + i * 16) * 32 + frag_off);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(sb_hi + (wn * 64 + j * 16) * 32 + frag_off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+            if (NPROD == 3) {
+                const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(sb_lo + (wn * 64 + j * 16) * 32 + frag_off);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 2 < ktiles) dma_wait<NDMA>(); else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        st_cur = (st_cur == 2) ? 0 : st_cur + 1;
+        st_fill = (st_fill == 2) ? 0 : st_fill + 1;
+    }
+    pairdist_epilogue<4, 4>(acc, tm * TM, tn * TN, wm * 64 + (lane >> 4) * 4, wn * 64 + (lane & 15), gsq, qsq, ng, nq, metric, out, blend);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,6 +499,24 @@ extern "C" int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x,
 static int launch_pairdist(hipStream_t st, const uint16_t* ghi, const uint16_t* glo, const float* gsq,
                            const uint16_t* qhi, const uint16_t* qlo, const float* qsq, int nq, int ng, int Kp,
                            int metric, bool split, float* out, PairBlend blend = PairBlend{nullptr, nullptr, nullptr, nullptr, 0}) {
+    static const bool no_dma = getenv("DALI_PAIRDIST_NODMA") != nullptr;
+    if (!no_dma && (long long)ng * Kp * 2 < 0x7ff00000ll && (long long)nq * Kp * 2 < 0x7ff00000ll) {
+        const int tm2 = (ng + 127) / 128, tn2 = (nq + 255) / 256;
+        const int grid2 = xcd_tile_grid(tm2, tn2);
+        if (split) {
+            const int lds = 3 * 2 * (128 + 256) * 32 * 2;                        // 3 stages x 48 KiB
+            static bool attr3 = false;
+            if (!attr3) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr3 = true; }
+            hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid2), dim3(512), lds, st, ghi, glo, qhi, qlo, gsq, qsq, ng, nq, Kp, metric, out, tm2, tn2, blend);
+        } else {
+            const int lds = 3 * (128 + 256) * 32 * 2;                            // 3 stages x 24 KiB
+            static bool attr1 = false;
+            if (!attr1) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr1 = true; }
+            hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid2), dim3(512), lds, st, ghi, ghi, qhi, qhi, gsq, qsq, ng, nq, Kp, metric, out, tm2, tn2, blend);
+        }
+        DALI_LAUNCH_CHECK();
+        return DALI_OK;
+    }
     const int tiles_m = (ng + 127) / 128, tiles_n = (nq + 127) / 128;
     const int grid = xcd_tile_grid(tiles_m, tiles_n);
     if (split) {

@@ -130,6 +130,27 @@ __device__ __forceinline__ void acc_coords(int& m_base, int& n_base) {
     n_base = (wave & 1) * (Cfg::TN / 2) + (lane & 15);
 }
 
+// ---- LDS-DMA helpers (buffer_load ... lds) shared by the conv and distance kernels ----
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+constexpr uint32_t DMA_OOB = 0x7ffffff0u;
+
+// wait until at most N of this wave's vector-memory operations (the LDS-DMA loads) are still in flight; also drains
+// this wave's LDS reads so the following barrier orders them against the next refill
+template <int N>
+__device__ __forceinline__ void dma_wait() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else static_assert(N == 0, "unsupported DMA count");
+}
+
+
 // XCD-aware block -> tile map.  Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the XCD group); each group
 // walks 64-tile "super-tiles" of SM x SN tiles so the 64 blocks resident on one XCD share SM A panels and SN B panels
 // through that XCD's L2, and the 8 XCDs work on neighbouring super-tiles (shared through the Infinity Cache).
