@@ -1219,6 +1219,8 @@ int conv_pick_cfg(int Cm, int P, int K) {
         if (Cm >= 512) return CONV_256x256;
         if (Cm >= 128) return CONV_128x256;             // Cm = 128 (layer2 3x3): -18 % against 128 x 128
     }
+    if (K >= 512 && P >= 16384 && Cm >= 256) return CONV_128x256;     // ViT linears (K = 768), layer4 conv3 / layer3 downsample
+
     return CONV_128;
 }
 int igemm_conv_stat_tiles(int Cm, int P, int K) {
