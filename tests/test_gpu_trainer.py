@@ -100,3 +100,37 @@ def test_getdcnn_full_model_forward_shapes(env):
     assert y.shape == (3, 2048) and torch.isfinite(y).all()
     with pytest.raises(NotImplementedError):
         Encoders.getDCNN([0], "osnet")
+
+
+def test_full_size_step_is_finite_and_bit_reproducible(env):
+    """configs[1] size (ResNet-50, 256 x 3 x 256 x 128, NC = 1024): properties that do not need the oracle at this size --
+    finite loss / gradients, an Adam-sized weight change, and bit-identical results when the same step is run on two
+    identically seeded replicas (every reduction in the path is fixed-order: no float atomics anywhere)."""
+    Encoders, _, T, _, _ = env
+    from daliid_amd.losses import LossHeads, _sample_weights
+    from daliid_amd.ops_eval import l2norm_rows
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    imgs = torch.randn(256, 3, 256, 128, device=dev, generator=gen)
+    labels = torch.arange(16, device=dev).repeat_interleave(16).to(torch.int32)
+    centers = l2norm_rows(torch.randn(1024, 2048, device=dev, generator=gen))
+    proxies = l2norm_rows(torch.randn(5120, 2048, device=dev, generator=gen))
+    w = _sample_weights(torch.randint(0, 6, (256,), generator=torch.Generator().manual_seed(1)), 10, 250, dev)
+    results = []
+    for _ in range(2):
+        online, momentum = Encoders.ResNet50ReID(device=dev, seed=12), Encoders.ResNet50ReID(device=dev, seed=12)
+        opt = torch.optim.Adam(online.parameters(), lr=3.5e-4, weight_decay=5e-4)
+        tr = T.trainer("Synthetic", None, "resnet50", {}, 256, 128, None, False, 1, opt, 16, 16, 0.05, 0.999, 0.4, 250, online, momentum, [0], "t")
+        heads = LossHeads(centers, np.arange(1024), proxies, np.repeat(np.arange(1024), 5), 0.05, 0.4, None)
+        online.train(); momentum.eval()
+        before = online.flat_params.clone()
+        acc = torch.zeros(6, device=dev)
+        stats = tr.train_step(heads, imgs, labels, w, acc)
+        results.append((online.flat_params.clone(), online.flat_grads.clone(), momentum.flat_params.clone(), acc.clone(), stats.clone()))
+        step = (online.flat_params - before).abs().max().item()
+        assert torch.isfinite(acc).all() and torch.isfinite(online.flat_grads).all() and torch.isfinite(online.flat_params).all()
+        assert 1e-4 < step < 1.1e-3, step                                     # Adam's first step moves every weight by ~lr
+        assert float(acc[2]) > 0 and float(acc[4]) == 1
+        del online, momentum, tr, opt
+    for a, b in zip(results[0], results[1]):
+        assert torch.equal(a, b)
