@@ -594,6 +594,129 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
+// k-tile of 64 (128-byte operand rows).  Measured with scripts/micro/dma_segments.hip: the L2 -> LDS path of a CU retires
+// about one cache line per 3 clocks whatever part of the line is used, so a [rows][32 bf16] k-tile (64 B = half a line per
+// row) feeds 70-79 GB/s per CU and a [rows][64 bf16] k-tile (a full 128-B line per row) 98-132 GB/s; the ablated 256 x 256
+// kernel (scripts/ablate_conv.py) spent 0.66 us per 32-deep k-step in the feed alone against 0.43 us of MFMA work.
+// Same wave grid, per-wave 64 x 64 sub-tile and epilogue as igemm_conv_wg_kernel; a DMA piece is 8 rows x 128 B, a stage is
+// (TM + TN) x 128 B, one barrier per 64 deep k-step (2 x 16 MFMAs per wave).  Swizzle: physical 16-byte chunk =
+// logical chunk ^ ((row >> 1) & 7): every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ... = 8 rows of one
+// chunk + 8 rows of the next) lands on 16 distinct 16-byte bank slots.  Needs Ck % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NW = WM * WN, NT = NW * 64;     // per-wave sub-tile 16 FM x 16 FN
+    constexpr int A_BLK = TM / 8 / NW, B_BLK = TN / 8 / NW, NDMA = A_BLK + B_BLK;
+    constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE_ELEMS = A_ELEMS + B_ELEMS;
+    constexpr int AHEAD = NSTAGE - 1;
+    static_assert(NW % 2 == 0 && TM % (8 * NW) == 0 && TN % (8 * NW) == 0, "DMA pieces must divide evenly over an even number of waves");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const GatherGeom g = a.g;
+    const int K = g.R * g.S * g.Ck;                    // weight row length
+    const int ktiles = (g.nr * g.ns * g.Ck) >> 6;      // taps actually visited (all of them unless g.sub)
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+    // LDS slot `lane` of piece q (rows 8q .. 8q+7) = row 8q + (lane >> 3), physical chunk lane & 7; q = wave + NW * i has the
+    // parity of the wave, so the logical chunk this lane fetches is the same for all of its pieces
+    const int r_in = lane >> 3;
+    const int kc = (lane & 7) ^ (((wave & 1) << 2) | (r_in >> 1));
+    uint32_t a_off[A_BLK];
+#pragma unroll
+    for (int i = 0; i < A_BLK; ++i) {
+        const int m = tm * TM + 8 * (wave + NW * i) + r_in;
+        a_off[i] = (m < a.Cm) ? (uint32_t)(m * K + kc * 8) * 2u : DMA_OOB;
+    }
+    int b_pix[B_BLK], b_h0[B_BLK], b_w0[B_BLK];
+#pragma unroll
+    for (int i = 0; i < B_BLK; ++i) {
+        const int p = tn * TN + 8 * (wave + NW * i) + r_in;
+        int n = 0, ho = 0, wo = 0;
+        const bool ok = p < a.P;
+        if (ok) decode_pixel(g, p, n, ho, wo);
+        if (g.sub) { ho = 2 * ho + g.oph; wo = 2 * wo + g.opw; }
+        if (g.mode == 0) { b_h0[i] = ho * g.stride - g.pad; b_w0[i] = wo * g.stride - g.pad; }
+        else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
+        if (!ok) b_h0[i] = -0x40000000;
+        b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;
+    }
+    int kr = g.r0, ks = g.s0, kc0 = 0;
+    const int ks_end = g.s0 + g.sstep * g.ns, kr_end = g.r0 + g.rstep * g.nr;
+    auto issue = [&](int stage) {
+        uint16_t* sa = smem + stage * STAGE_ELEMS;
+        uint16_t* sb = sa + A_ELEMS;
+        const int kbase = ((kr * g.S + ks) * g.Ck + kc0) * 2;
+#pragma unroll
+        for (int i = 0; i < A_BLK; ++i) {
+            const uint32_t off = (a_off[i] == DMA_OOB) ? DMA_OOB : a_off[i] + (uint32_t)kbase;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (wave + NW * i) * 512), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_BLK; ++i) {
+            int hi, wi;
+            bool ok = true;
+            if (g.mode == 0) { hi = b_h0[i] + kr; wi = b_w0[i] + ks; }
+            else {
+                const int th = b_h0[i] - kr, tw = b_w0[i] - ks;
+                ok = (th >= 0) && (tw >= 0);
+                if (g.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                else { hi = th; wi = tw; }
+            }
+            ok = ok && ((unsigned)hi < (unsigned)g.Hin) && ((unsigned)wi < (unsigned)g.Win);
+            const uint32_t off = ok ? (uint32_t)(b_pix[i] + hi * g.row_pitch + wi * g.pix_pitch + kc0) * 2u : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + NW * i) * 512), 16, off, 0, 0, 0);
+        }
+        ks += g.sstep;                                   // taps fastest, channel block outermost (see igemm_conv_dma_kernel)
+        if (ks >= ks_end) { ks = g.s0; kr += g.rstep; if (kr >= kr_end) { kr = g.r0; kc0 += 64; } }
+    };
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // fragment of the first 32 k: row lane & 15, logical chunk lane >> 4; the second 32 k are chunk + 4 = physical chunk ^ 4
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);
+    const int a_row0 = wm * (16 * FM), b_row0 = wn * (16 * FN);
+    int issued = 0;
+    for (; issued < AHEAD && issued < ktiles; ++issued) issue(issued);
+    if (issued == 2) dma_wait<NDMA>(); else dma_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    int st_cur = 0, st_fill = AHEAD % NSTAGE;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        if (kt + AHEAD < ktiles) issue(st_fill);
+        const uint16_t* sa = smem + st_cur * STAGE_ELEMS;
+        const uint16_t* sb = sa + A_ELEMS;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int fo = frag_off ^ (h << 5);
+            bf16x8_t fa[FM];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + (a_row0 + i * 16) * 64 + fo);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(sb + (b_row0 + j * 16) * 64 + fo);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+            }
+        }
+        // retire tile kt+1: only the youngest tile (if any beyond kt+1) may still be in flight
+        const int left = ktiles - 1 - kt;
+        if (AHEAD == 2 && left >= 2) dma_wait<NDMA>(); else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
+        st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
+    }
+    __syncthreads();
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT>(a, acc, tm, tn, smem, wm, wn);
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: M = Cm (channels of dY), N = R*S*Ck, K = pixels.  Both operands are stored pixel-major, so the
 // MFMA fragments (8 consecutive k per lane) are produced by ds_read_b64_tr_b16 transposing reads.
 // LDS image per operand and stage: [32 pixels][128 channels] bf16 (256-byte rows); the 32-byte chunk index is
@@ -1207,6 +1330,13 @@ static int conv_cfg_override() {
     if (v == -2) { const char* e = getenv("DALI_CONV_CFG"); v = e ? atoi(e) : -1; }
     return v;
 }
+// DALI_CONV_K64 (A/B aid): 0 = k-tile 32 kernels only, 2 (default) = k-tile 64 kernels on the long-K layers,
+// 4 / 3 = k-tile 64 wherever Ck % 64 == 0, the 128 x 128 tile with a 2- / 3-stage ring
+static int conv_k64_mode() {
+    static int v = -1;
+    if (v == -1) { const char* e = getenv("DALI_CONV_K64"); v = e ? atoi(e) : 2; }
+    return v;
+}
 int conv_pick_cfg(int Cm, int P, int K) {
     if (Cm <= 64) return CONV_NARROW;
     const int ov = conv_cfg_override();
@@ -1314,7 +1444,35 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     }
     {
     ProfScope prof_scope(st, 0, 2.0 * a.Cm * (double)a.P * K);
-    if (narrow) {
+    // k-tile 64 pays where the main loop dominates (K >= 1024) and the tile leaves one workgroup per CU anyway; with a short K
+    // or the 128 x 128 tile the smaller k-tile's 2-3 co-resident workgroups overlap their epilogues better (measured per layer:
+    // 256 x 256 -12..-15 %, 128 x 256 at Cm >= 256 -8..-14 %; Cm = 128 or K = 512: +15..+25 %)
+    int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
+    if (k64 == 2 && !(K >= 1024 && (cfg == CONV_256x256 || (cfg == CONV_128x256 && a.Cm >= 256)))) k64 = 0;
+    if (k64 && cfg == CONV_256x256) {
+        static bool attr_set = false;
+        const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
+        const int lds = (256 + 256) * 64 * 2 * 2;
+        // (8 waves with 128 x 64 per wave, 25 % fewer LDS fragment bytes, 192 VGPRs: measured 3-5 % slower than 16 waves of 64 x 64)
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+    } else if (k64 && cfg == CONV_128x256) {
+        static bool attr_set = false;
+        const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
+        const int lds = (128 + 256) * 64 * 2 * 3;
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+    } else if (k64 && cfg == CONV_128) {
+        static bool attr_set = false;
+        const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 2 * 2));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 2 * 3));
+            attr_set = true;
+        }
+        if (k64 == 3) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 3, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 2, st, args, tiles_m, tiles_n);
+    } else if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
