@@ -29,9 +29,10 @@ _SIGNATURES = {
     "dali_l2norm_rows": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "dali_l2norm_rows_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "dali_pairdist": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "dali_pairdist_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "dali_pairdist_prepared": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                               c_int, c_int, c_void_p],
+    "dali_pairdist_operand_bytes": [c_int, c_int, c_int],
+    "dali_pairdist_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "dali_pairdist_prepared": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_void_p],
     "dali_rank_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_conv2d_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p],
@@ -97,7 +98,7 @@ _SIGNATURES = {
     "dali_vit_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "dali_vit_backward": [c_void_p, c_void_p, c_void_p],
 }
-_RESTYPES = {"dali_last_error": ctypes.c_char_p}
+_RESTYPES = {"dali_last_error": ctypes.c_char_p, "dali_pairdist_operand_bytes": ctypes.c_size_t}
 
 _lock = threading.Lock()
 _lib = None

@@ -7,13 +7,16 @@
 namespace dali {
 
 // ------------------------------------------------------------------------------------------------
-// Row pre-pass: one wave64 per row.  Optionally normalises (y = x / (|x| + eps)), emits the bf16 "hi"
-// part and the bf16 residual "lo" (y - hi) zero-padded to Kp columns, |y|^2, and/or the fp32 row.
+// Row pre-pass: one wave64 per row.  Optionally normalises (y = x / (|x| + eps)), emits the bf16 operand image
+// (zero-padded to Kp columns), |y|^2, and/or the fp32 row.  Operand image layouts (what the distance kernels DMA):
+//   layout 1 (bf16):    [n][Kp] bf16, Kp = roundup(d, 64): a 64-deep k-step of one row is one 128-byte cache line;
+//   layout 3 (bf16 x3): [n][Kp/32][hi 32 | lo 32] bf16, Kp = roundup(d, 32), lo = bf16(y - hi): the hi and lo parts of a
+//                       32-deep k-step of one row share one 128-byte line (the L2 -> LDS path retires whole lines, see conv.hip).
 // HBM-bound: reads 4 B/elem once, writes 2-4 B/elem.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, int n, int d, int Kp,
-                                                         int normalize, float eps, uint16_t* __restrict__ hi,
-                                                         uint16_t* __restrict__ lo, float* __restrict__ sq,
+                                                         int normalize, float eps, uint16_t* __restrict__ img,
+                                                         int layout, float* __restrict__ sq,
                                                          float* __restrict__ yout, float* __restrict__ norms) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,18 +49,21 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict_
             for (int t = 0; t < 4; ++t)
                 if (c + t < d) yout[(size_t)row * d + c + t] = v[t];
         }
-        if (hi) {
+        if (img) {
             uint16_t h[4], l[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 h[t] = f32_to_bf16_bits(v[t]);
                 l[t] = f32_to_bf16_bits(v[t] - bf16_bits_to_f32(h[t]));
             }
-            uint2 hv = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-            *reinterpret_cast<uint2*>(hi + (size_t)row * Kp + c) = hv;
-            if (lo) {
-                uint2 lv = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
-                *reinterpret_cast<uint2*>(lo + (size_t)row * Kp + c) = lv;
+            const uint2 hv = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            if (layout == 3) {
+                uint16_t* dst = img + (size_t)row * (2 * Kp) + (c >> 5) * 64 + (c & 31);
+                const uint2 lv = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                *reinterpret_cast<uint2*>(dst) = hv;
+                *reinterpret_cast<uint2*>(dst + 32) = lv;
+            } else {
+                *reinterpret_cast<uint2*>(img + (size_t)row * Kp + c) = hv;
             }
         }
     }
@@ -88,14 +94,13 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 template <int NPROD>
 struct PairCfg { using type = GemmCfg<128, 128, (NPROD == 3 ? 2 : 1), (NPROD == 3 ? 2 : 1), NPROD>; };
 
-struct RowLoader {
-    const uint16_t* p0; const uint16_t* p1;
-    int row0, nrows, Kp;
+struct RowLoader {                       // 32-deep k-tile kt of row `row` of an operand image; arr 1 = the lo part (layout 3)
+    const uint16_t* p;
+    int row0, nrows, pitch, kstep;
     __device__ __forceinline__ uint4 operator()(int arr, int row, int kt, int kc) const {
         const int r = row0 + row;
         if (r >= nrows) return make_uint4(0, 0, 0, 0);
-        const uint16_t* p = arr ? p1 : p0;
-        return *reinterpret_cast<const uint4*>(p + (size_t)r * Kp + kt * 32 + kc * 8);
+        return *reinterpret_cast<const uint4*>(p + (size_t)r * pitch + kt * kstep + arr * 32 + kc * 8);
     }
 };
 
@@ -167,8 +172,7 @@ __device__ __forceinline__ void pairdist_epilogue(f32x4_t (&acc)[FM][FN], int g_
 }
 
 template <int NPROD>
-__global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restrict__ Ghi, const uint16_t* __restrict__ Glo,
-                                                       const uint16_t* __restrict__ Qhi, const uint16_t* __restrict__ Qlo,
+__global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
                                                        const float* __restrict__ gsq, const float* __restrict__ qsq,
                                                        int ng, int nq, int Kp, int metric, float* out,
                                                        int tiles_m, int tiles_n, PairBlend blend) {
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
     for (int i = 0; i < Cfg::FM; ++i)
 #pragma unroll
         for (int j = 0; j < Cfg::FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    RowLoader la{Ghi, Glo, tm * Cfg::TM, ng, Kp};
-    RowLoader lb{Qhi, Qlo, tn * Cfg::TN, nq, Kp};
+    RowLoader la{G, tm * Cfg::TM, ng, NPROD == 3 ? 2 * Kp : Kp, NPROD == 3 ? 64 : 32};
+    RowLoader lb{Q, tn * Cfg::TN, nq, NPROD == 3 ? 2 * Kp : Kp, NPROD == 3 ? 64 : 32};
     gemm_mainloop<Cfg>(acc, la, lb, Kp / 32, smem);
 
     int mb, nb;
@@ -191,58 +195,51 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
 }
 
 // LDS-DMA version (what the launcher uses when the operands fit 32-bit buffer offsets): 128 gallery rows x 256 query
-// rows per 8-wave block (wave (wm, wn) of the 2 x 4 grid owns 64 x 64), every operand image [rows][32] travels HBM/L2 -> LDS
-// with buffer_load_dwordx4 ... lds (no VGPR staging), 3-stage ring with counted vmcnt.  NPROD = 3: hi and lo images of both
-// sides (48 KiB per stage); per k-step a wave reads 16 fragments for 48 MFMAs -- three times the MFMA work per DMA piece of
-// the convolution kernels, which are issue-bound.
+// rows per 8-wave block (wave (wm, wn) of the 2 x 4 grid owns 64 x 64).  A k-step takes one 128-byte line of every operand
+// row ([hi 32 | lo 32] for NPROD = 3, 64 consecutive k for NPROD = 1) by buffer_load_dwordx4 ... lds (a DMA piece = 8 rows,
+// no VGPR staging) into a [rows][64] LDS image (physical 16-byte chunk = logical ^ ((row >> 1) & 7), as the k-tile-64 conv
+// kernel); 48 KiB per stage, 3-stage ring with counted vmcnt.  Per k-step a wave reads 16 fragments for 48 (NPROD = 3: hi.hi +
+// hi.lo + lo.hi) or 32 MFMAs.
+// Measured and not kept: the two waves of a SIMD issuing their DMA pieces at different points of the k-step (no change), and
+// a software-pipelined loop (wait + barrier half way through the k-step, next tile's first fragments fetched under the second
+// half of the MFMAs: the DMA lead shrinks from two k-steps to one, +5 % / +18 % time).
 template <int NPROD>
-__global__ __launch_bounds__(512) void pairdist_dma_kernel(const uint16_t* __restrict__ Ghi, const uint16_t* __restrict__ Glo,
-                                                           const uint16_t* __restrict__ Qhi, const uint16_t* __restrict__ Qlo,
+__global__ __launch_bounds__(512) void pairdist_dma_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
                                                            const float* __restrict__ gsq, const float* __restrict__ qsq,
-                                                           int ng, int nq, int Kp, int metric, float* out,
+                                                           int ng, int nq, int pitch, int ktiles, int metric, float* out,
                                                            int tiles_m, int tiles_n, PairBlend blend) {
-    constexpr int TM = 128, TN = 256, NARR = NPROD == 3 ? 2 : 1;
-    constexpr int A_ELEMS = TM * 32, B_ELEMS = TN * 32, STAGE = NARR * (A_ELEMS + B_ELEMS);
-    constexpr int NBLK = NARR * (TM + TN) / 16, NDMA = NBLK / 8;                 // 1 KiB DMA blocks per stage / per wave
+    constexpr int TM = 128, TN = 256;
+    constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int A_PIECES = TM / 8, NDMA = (TM + TN) / 8 / 8;                   // 1 KiB DMA pieces: 16 of A, 6 per wave
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
     if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int ktiles = Kp >> 5;
-    const __amdgpu_buffer_rsrc_t rs[4] = {
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ghi), 0, ng * Kp * 2, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Glo), 0, ng * Kp * 2, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Qhi), 0, nq * Kp * 2, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Qlo), 0, nq * Kp * 2, 0x00020000)};
-    // this wave's DMA blocks: q = wave + 8*i; LDS order inside a stage: [A hi][A lo][B hi][B lo] (lo only for NPROD = 3)
-    const int r_in = lane >> 2;
-    const int kc = (lane & 3) ^ lds_swz(r_in);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G), 0, ng * pitch * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Q), 0, nq * pitch * 2, 0x00020000);
+    // this wave's pieces: q = wave + 8*i; q < 16: rows 8q.. of the gallery tile, else rows 8(q-16).. of the query tile; both
+    // piece indices have the wave's parity, so one logical chunk per lane serves all of them
+    const int r_in = lane >> 3;
+    const int kc = (lane & 7) ^ (((wave & 1) << 2) | (r_in >> 1));
     uint32_t off[NDMA];
-    int arr[NDMA];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
         const int q = wave + 8 * i;
-        const int a_blocks = NARR * (TM / 16);
-        const bool is_a = q < a_blocks;
-        const int qa = is_a ? q : q - a_blocks;
-        const int rows16 = is_a ? TM / 16 : TN / 16;
-        const int which = qa / rows16, blk = qa - which * rows16;                // which: 0 hi, 1 lo
-        const int row = (is_a ? tm * TM : tn * TN) + blk * 16 + r_in;
-        arr[i] = (is_a ? 0 : 2) + which;
-        off[i] = (row < (is_a ? ng : nq)) ? (uint32_t)(row * Kp + kc * 8) * 2u : DMA_OOB;
+        const bool is_a = q < A_PIECES;
+        const int row = is_a ? tm * TM + q * 8 + r_in : tn * TN + (q - A_PIECES) * 8 + r_in;
+        off[i] = (row < (is_a ? ng : nq)) ? (uint32_t)(row * pitch + kc * 8) * 2u : DMA_OOB;
     }
+    static_assert(A_PIECES % 8 == 0, "a wave's piece i is a gallery piece for every wave or for none");
     auto issue = [&](int kt, int stage) {
         uint16_t* base = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const uint32_t o = (off[i] == DMA_OOB) ? DMA_OOB : off[i] + (uint32_t)(kt * 64);
+            const uint32_t o = (off[i] == DMA_OOB) ? DMA_OOB : off[i] + (uint32_t)(kt * 128);
             uint16_t* dst = base + (wave + 8 * i) * 512;
-            if (arr[i] == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[0], (lds_void_ptr)dst, 16, o, 0, 0, 0);
-            else if (arr[i] == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[1], (lds_void_ptr)dst, 16, o, 0, 0, 0);
-            else if (arr[i] == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[2], (lds_void_ptr)dst, 16, o, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[3], (lds_void_ptr)dst, 16, o, 0, 0, 0);
+            if (8 * i + 7 < A_PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_void_ptr)dst, 16, o, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)dst, 16, o, 0, 0, 0);
         }
     };
     f32x4_t acc[4][4];
@@ -250,7 +247,7 @@ __global__ __launch_bounds__(512) void pairdist_dma_kernel(const uint16_t* __res
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int frag_off = (lane & 15) * 32 + (((lane >> 4) ^ lds_swz(lane & 15)) << 3);
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);   // first half; second half = ^ 32
     issue(0, 0);
     if (ktiles > 1) issue(1, 1);
     if (ktiles > 1) dma_wait<NDMA>(); else dma_wait<0>();
@@ -258,27 +255,26 @@ __global__ __launch_bounds__(512) void pairdist_dma_kernel(const uint16_t* __res
     int st_cur = 0, st_fill = 2;
     for (int kt = 0; kt < ktiles; ++kt) {
         if (kt + 2 < ktiles) issue(kt + 2, st_fill);
-        const uint16_t* sa_hi = smem + st_cur * STAGE;
-        const uint16_t* sa_lo = sa_hi + A_ELEMS;                                 // valid for NPROD = 3 only
-        const uint16_t* sb_hi = sa_hi + NARR * A_ELEMS;
-        const uint16_t* sb_lo = sb_hi + B_ELEMS;
-        bf16x8_t ah[4], al[4];
+        const uint16_t* sa = smem + st_cur * STAGE;
+        const uint16_t* sb = sa + A_ELEMS;
+        bf16x8_t a0[4], a1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ah[i] = *reinterpret_cast<const bf16x8_t*>(sa_hi + (wm * 64 + i * 16) * 32 + frag_off);
-            if (NPROD == 3) al[i] = *reinterpret_cast<const bf16x8_t*>(sa_lo + (wm * 64 + i * 16) * 32 + frag_off);
+            a0[i] = *reinterpret_cast<const bf16x8_t*>(sa + (wm * 64 + i * 16) * 64 + frag_off);
+            a1[i] = *reinterpret_cast<const bf16x8_t*>(sa + (wm * 64 + i * 16) * 64 + (frag_off ^ 32));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(sb_hi + (wn * 64 + j * 16) * 32 + frag_off);
+            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(sb + (wn * 64 + j * 16) * 64 + frag_off);
+            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(sb + (wn * 64 + j * 16) * 64 + (frag_off ^ 32));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
-            if (NPROD == 3) {
-                const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(sb_lo + (wn * 64 + j * 16) * 32 + frag_off);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0, acc[i][j], 0, 0, 0);
+                if (NPROD == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b1, acc[i][j], 0, 0, 0);       // hi . lo
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b0, acc[i][j], 0, 0, 0);       // lo . hi
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1, acc[i][j], 0, 0, 0);       // next 32 k
                 }
             }
         }

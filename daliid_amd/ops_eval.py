@@ -44,27 +44,28 @@ def pairdist(q, g, metric="cosine", precision="bf16x3", normalize=False, out=Non
 
 
 class PreparedRows:
-    """bf16 hi/lo operand image of a feature matrix (dali_pairdist_prepare)."""
+    """bf16 operand image of a feature matrix (dali_pairdist_prepare): opaque bytes + the squared row norms."""
 
     def __init__(self, x, normalize=False, precision="bf16x3"):
         assert x.dim() == 2
         self.n, self.d = x.shape
-        kp = (self.d + 31) // 32 * 32
-        self.hi = torch.empty(self.n, kp, device=x.device, dtype=torch.int16)
-        self.lo = torch.empty(self.n, kp, device=x.device, dtype=torch.int16) if precision == "bf16x3" else None
+        self.precision = precision
+        L = _lib.lib()
+        nbytes = int(L.dali_pairdist_operand_bytes(self.n, self.d, _PREC[precision]))
+        self.image = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8)
         self.sq = torch.empty(max(self.n, 1), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().dali_pairdist_prepare(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, torch.float32, "x"),
-                                                     self.n, self.d, int(bool(normalize)), _lib.ptr(self.hi),
-                                                     _lib.ptr(self.lo), _lib.ptr(self.sq)), "dali_pairdist_prepare")
+        _lib.check(L.dali_pairdist_prepare(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, torch.float32, "x"), self.n, self.d,
+                                           int(bool(normalize)), _PREC[precision], _lib.ptr(self.image), _lib.ptr(self.sq)),
+                   "dali_pairdist_prepare")
 
 
 def pairdist_prepared(qp, gp, metric="cosine", out=None):
-    assert qp.d == gp.d and (qp.lo is None) == (gp.lo is None)
+    assert qp.d == gp.d and qp.precision == gp.precision
     if out is None:
-        out = torch.empty(qp.n, gp.n, device=qp.hi.device, dtype=torch.float32)
-    _lib.check(_lib.lib().dali_pairdist_prepared(_lib.ctx(out.device), _lib.stream_ptr(), _lib.ptr(qp.hi), _lib.ptr(qp.lo),
-                                                  _lib.ptr(qp.sq), _lib.ptr(gp.hi), _lib.ptr(gp.lo), _lib.ptr(gp.sq),
-                                                  qp.n, gp.n, qp.d, _METRIC[metric], _lib.ptr(out, torch.float32, "out")),
+        out = torch.empty(qp.n, gp.n, device=qp.image.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dali_pairdist_prepared(_lib.ctx(out.device), _lib.stream_ptr(), _lib.ptr(qp.image), _lib.ptr(qp.sq),
+                                                  _lib.ptr(gp.image), _lib.ptr(gp.sq), qp.n, gp.n, qp.d, _METRIC[metric],
+                                                  _PREC[qp.precision], _lib.ptr(out, torch.float32, "out")),
                "dali_pairdist_prepared")
     return out
 

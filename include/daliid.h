@@ -68,18 +68,20 @@ int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x, const floa
 /* out[nq,ng] (fp32, row-major) = metric(Q[nq,d], G[ng,d]); fp32 inputs.
  * normalize != 0 fuses the row normalisation of validateModels.py:41-42 into the operand pre-pass
  * (the reference sequence normalise -> 1 - q@g.T becomes one call).
- * Workspace: (nq+ng) * roundup(d,32) * 4 bytes (bf16 hi+lo copies) + (nq+ng)*4. */
+ * Workspace: the two operand images (dali_pairdist_operand_bytes) + (nq+ng)*4. */
 int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
                   int metric, int precision, int normalize, float* out);
 
 /* The two halves of dali_pairdist, for callers that reuse a prepared gallery against many query sets:
- * prepare: X[n,d] fp32 -> bf16 hi (and residual lo, nullable => single-bf16 mode) padded to
- * Kp = roundup(d,32) columns, plus |row|^2 (after the optional normalisation). */
-int dali_pairdist_prepare(dali_ctx* ctx, void* stream, const float* X, int n, int d, int normalize,
-                          uint16_t* hi, uint16_t* lo, float* sq);
-int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const uint16_t* q_hi, const uint16_t* q_lo,
-                           const float* q_sq, const uint16_t* g_hi, const uint16_t* g_lo, const float* g_sq,
-                           int nq, int ng, int d, int metric, float* out);
+ * prepare: X[n,d] fp32 -> the bf16 operand image the distance kernel reads (dali_pairdist_operand_bytes(n, d, precision) bytes,
+ * 16-byte aligned; opaque: DALI_PREC_BF16X3 interleaves the bf16 hi part and the bf16 residual per 32 columns so that one
+ * k-step of a row is one 128-byte cache line, DALI_PREC_BF16 pads the row to 64 columns) plus |row|^2 (after the optional
+ * normalisation).  Both sides of dali_pairdist_prepared must have been prepared with the same precision. */
+size_t dali_pairdist_operand_bytes(int n, int d, int precision);
+int dali_pairdist_prepare(dali_ctx* ctx, void* stream, const float* X, int n, int d, int normalize, int precision,
+                          void* image, float* sq);
+int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const void* q_image, const float* q_sq, const void* g_image,
+                           const float* g_sq, int nq, int ng, int d, int metric, int precision, float* out);
 
 /* Two-model distance fusion (evaluateCleanATModels.py:103-160): with inout holding the first model's distmat d1
  * (dali_pairdist), computes the second model's d2 = 1 - q.g on the fly and stores
