@@ -477,7 +477,7 @@ extern "C" int dali_l2norm_rows(dali_ctx* ctx, void* stream, const float* x, int
     DALI_REQUIRE(n >= 0 && d > 0, "dali_l2norm_rows: bad shape n=%d d=%d", n, d);
     if (n == 0) return DALI_OK;
     hipLaunchKernelGGL(rows_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, n, d, (d + 3) & ~3, 1, eps,
-                       (uint16_t*)nullptr, (uint16_t*)nullptr, (float*)nullptr, y, norms);
+                       (uint16_t*)nullptr, 0, (float*)nullptr, y, norms);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -492,24 +492,26 @@ extern "C" int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x,
     return DALI_OK;
 }
 
-static int launch_pairdist(hipStream_t st, const uint16_t* ghi, const uint16_t* glo, const float* gsq,
-                           const uint16_t* qhi, const uint16_t* qlo, const float* qsq, int nq, int ng, int Kp,
-                           int metric, bool split, float* out, PairBlend blend = PairBlend{nullptr, nullptr, nullptr, nullptr, 0}) {
+// operand image geometry (rows_prep_kernel): columns padded to Kp, `pitch` bf16 elements per row
+static inline int pair_kp(int d, bool split) { return split ? (d + 31) & ~31 : (d + 63) & ~63; }
+static inline int pair_pitch(int d, bool split) { return split ? 2 * pair_kp(d, true) : pair_kp(d, false); }
+
+static int launch_pairdist(hipStream_t st, const uint16_t* g_img, const float* gsq, const uint16_t* q_img, const float* qsq, int nq, int ng,
+                           int d, int metric, bool split, float* out, PairBlend blend = PairBlend{nullptr, nullptr, nullptr, nullptr, 0}) {
     static const bool no_dma = getenv("DALI_PAIRDIST_NODMA") != nullptr;
-    if (!no_dma && (long long)ng * Kp * 2 < 0x7ff00000ll && (long long)nq * Kp * 2 < 0x7ff00000ll) {
+    const int Kp = pair_kp(d, split), pitch = pair_pitch(d, split);
+    if (!no_dma && (long long)ng * pitch * 2 < 0x7ff00000ll && (long long)nq * pitch * 2 < 0x7ff00000ll) {
         const int tm2 = (ng + 127) / 128, tn2 = (nq + 255) / 256;
         const int grid2 = xcd_tile_grid(tm2, tn2);
-        if (split) {
-            const int lds = 3 * 2 * (128 + 256) * 32 * 2;                        // 3 stages x 48 KiB
-            static bool attr3 = false;
-            if (!attr3) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr3 = true; }
-            hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid2), dim3(512), lds, st, ghi, glo, qhi, qlo, gsq, qsq, ng, nq, Kp, metric, out, tm2, tn2, blend);
-        } else {
-            const int lds = 3 * (128 + 256) * 32 * 2;                            // 3 stages x 24 KiB
-            static bool attr1 = false;
-            if (!attr1) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr1 = true; }
-            hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid2), dim3(512), lds, st, ghi, ghi, qhi, qhi, gsq, qsq, ng, nq, Kp, metric, out, tm2, tn2, blend);
+        const int lds = 3 * (128 + 256) * 64 * 2;                                // 3 stages x 48 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
         }
+        if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid2), dim3(512), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 32, metric, out, tm2, tn2, blend);
+        else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid2), dim3(512), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 64, metric, out, tm2, tn2, blend);
         DALI_LAUNCH_CHECK();
         return DALI_OK;
     }
@@ -519,42 +521,59 @@ static int launch_pairdist(hipStream_t st, const uint16_t* ghi, const uint16_t* 
         using Cfg = PairCfg<3>::type;
         DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_kernel<3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        hipLaunchKernelGGL(pairdist_kernel<3>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, ghi, glo, qhi, qlo, gsq, qsq, ng, nq,
-                           Kp, metric, out, tiles_m, tiles_n, blend);
+        hipLaunchKernelGGL(pairdist_kernel<3>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, g_img, q_img, gsq, qsq, ng, nq, Kp, metric, out, tiles_m, tiles_n, blend);
     } else {
         using Cfg = PairCfg<1>::type;
-        hipLaunchKernelGGL(pairdist_kernel<1>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, ghi, ghi, qhi, qhi, gsq, qsq, ng, nq,
-                           Kp, metric, out, tiles_m, tiles_n, blend);
+        hipLaunchKernelGGL(pairdist_kernel<1>, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, g_img, q_img, gsq, qsq, ng, nq, Kp, metric, out, tiles_m, tiles_n, blend);
     }
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 
-extern "C" int dali_pairdist_prepare(dali_ctx* ctx, void* stream, const float* X, int n, int d, int normalize,
-                                     uint16_t* hi, uint16_t* lo, float* sq) {
-    DALI_REQUIRE(ctx && X && hi && sq, "dali_pairdist_prepare: null argument");
+extern "C" size_t dali_pairdist_operand_bytes(int n, int d, int precision) {
+    if (n <= 0 || d <= 0) return 0;
+    return (size_t)n * pair_pitch(d, precision == DALI_PREC_BF16X3) * sizeof(uint16_t);
+}
+
+extern "C" int dali_pairdist_prepare(dali_ctx* ctx, void* stream, const float* X, int n, int d, int normalize, int precision,
+                                     void* image, float* sq) {
+    DALI_REQUIRE(ctx && X && image && sq, "dali_pairdist_prepare: null argument");
     DALI_REQUIRE(n >= 0 && d > 0, "dali_pairdist_prepare: bad shape n=%d d=%d", n, d);
-    DALI_REQUIRE((reinterpret_cast<uintptr_t>(hi) & 15) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15) == 0,
-                 "dali_pairdist_prepare: hi/lo must be 16-byte aligned");
+    DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist_prepare: bad precision %d", precision);
+    DALI_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, "dali_pairdist_prepare: the operand image must be 16-byte aligned");
     if (n == 0) return DALI_OK;
-    const int Kp = (d + 31) & ~31;
-    hipLaunchKernelGGL(rows_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, n, d, Kp, normalize, 0.0f,
-                       hi, lo, sq, (float*)nullptr, (float*)nullptr);
+    const bool split = precision == DALI_PREC_BF16X3;
+    hipLaunchKernelGGL(rows_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, n, d, pair_kp(d, split), normalize, 0.0f,
+                       static_cast<uint16_t*>(image), split ? 3 : 1, sq, (float*)nullptr, (float*)nullptr);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 
-extern "C" int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const uint16_t* q_hi, const uint16_t* q_lo,
-                                      const float* q_sq, const uint16_t* g_hi, const uint16_t* g_lo, const float* g_sq,
-                                      int nq, int ng, int d, int metric, float* out) {
-    DALI_REQUIRE(ctx && q_hi && g_hi && q_sq && g_sq && out, "dali_pairdist_prepared: null argument");
-    DALI_REQUIRE((q_lo == nullptr) == (g_lo == nullptr), "dali_pairdist_prepared: q_lo and g_lo must both be set or both null");
+extern "C" int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const void* q_image, const float* q_sq, const void* g_image,
+                                      const float* g_sq, int nq, int ng, int d, int metric, int precision, float* out) {
+    DALI_REQUIRE(ctx && q_image && g_image && q_sq && g_sq && out, "dali_pairdist_prepared: null argument");
     DALI_REQUIRE(nq >= 0 && ng >= 0 && d > 0, "dali_pairdist_prepared: bad shape nq=%d ng=%d d=%d", nq, ng, d);
     DALI_REQUIRE(metric == DALI_METRIC_COSINE || metric == DALI_METRIC_L2SQ || metric == DALI_METRIC_DOT, "dali_pairdist_prepared: bad metric %d", metric);
+    DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist_prepared: bad precision %d", precision);
     DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist_prepared: out must be 16-byte aligned");
     if (nq == 0 || ng == 0) return DALI_OK;
-    return launch_pairdist((hipStream_t)stream, g_hi, g_lo, g_sq, q_hi, q_lo, q_sq, nq, ng, (d + 31) & ~31, metric,
-                           q_lo != nullptr, out);
+    return launch_pairdist((hipStream_t)stream, static_cast<const uint16_t*>(g_image), g_sq, static_cast<const uint16_t*>(q_image), q_sq, nq, ng, d,
+                           metric, precision == DALI_PREC_BF16X3, out);
+}
+
+// gallery image, query image and the squared norms in the context workspace
+static int prepare_both(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d, int precision, int normalize,
+                        uint16_t*& g_img, uint16_t*& q_img, float*& sq) {
+    const size_t g_bytes = align_up(dali_pairdist_operand_bytes(ng, d, precision), 256);
+    const size_t q_bytes = align_up(dali_pairdist_operand_bytes(nq, d, precision), 256);
+    char* ws = static_cast<char*>(workspace(ctx, g_bytes + q_bytes + align_up(((size_t)nq + ng) * sizeof(float), 256)));
+    if (!ws) return DALI_ERR_NOMEM;
+    g_img = reinterpret_cast<uint16_t*>(ws);
+    q_img = reinterpret_cast<uint16_t*>(ws + g_bytes);
+    sq = reinterpret_cast<float*>(ws + g_bytes + q_bytes);
+    int rc = dali_pairdist_prepare(ctx, stream, G, ng, d, normalize, precision, g_img, sq);          // gallery rows first
+    if (rc != DALI_OK) return rc;
+    return dali_pairdist_prepare(ctx, stream, Q, nq, d, normalize, precision, q_img, sq + ng);
 }
 
 extern "C" int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
@@ -565,23 +584,11 @@ extern "C" int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const 
     DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist: bad precision %d", precision);
     DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist: out must be 16-byte aligned");
     if (nq == 0 || ng == 0) return DALI_OK;
-    const int Kp = (d + 31) & ~31;
-    const bool split = precision == DALI_PREC_BF16X3;
-    const size_t rows = (size_t)nq + ng;
-    const size_t arr_bytes = align_up(rows * Kp * sizeof(uint16_t), 256);
-    const size_t total = arr_bytes * (split ? 2 : 1) + align_up(rows * sizeof(float), 256);
-    char* ws = static_cast<char*>(workspace(ctx, total));
-    if (!ws) return DALI_ERR_NOMEM;
-    uint16_t* hi = reinterpret_cast<uint16_t*>(ws);
-    uint16_t* lo = split ? reinterpret_cast<uint16_t*>(ws + arr_bytes) : nullptr;
-    float* sq = reinterpret_cast<float*>(ws + arr_bytes * (split ? 2 : 1));
-    uint16_t* qhi = hi + (size_t)ng * Kp;
-    uint16_t* qlo = lo ? lo + (size_t)ng * Kp : nullptr;
-    int rc = dali_pairdist_prepare(ctx, stream, G, ng, d, normalize, hi, lo, sq);       // gallery rows first
+    uint16_t *g_img, *q_img;
+    float* sq;
+    const int rc = prepare_both(ctx, stream, Q, G, nq, ng, d, precision, normalize, g_img, q_img, sq);
     if (rc != DALI_OK) return rc;
-    rc = dali_pairdist_prepare(ctx, stream, Q, nq, d, normalize, qhi, qlo, sq + ng);
-    if (rc != DALI_OK) return rc;
-    return launch_pairdist((hipStream_t)stream, hi, lo, sq, qhi, qlo, sq + ng, nq, ng, Kp, metric, split, out);
+    return launch_pairdist((hipStream_t)stream, g_img, sq, q_img, sq + ng, nq, ng, d, metric, precision == DALI_PREC_BF16X3, out);
 }
 
 extern "C" int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
@@ -595,23 +602,11 @@ extern "C" int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, 
                  "dali_pairdist_blend: the four magnitude vectors must be all set or all null");
     DALI_REQUIRE((reinterpret_cast<uintptr_t>(inout) & 15) == 0, "dali_pairdist_blend: inout must be 16-byte aligned");
     if (nq == 0 || ng == 0) return DALI_OK;
-    const int Kp = (d + 31) & ~31;
-    const bool split = precision == DALI_PREC_BF16X3;
-    const size_t rows = (size_t)nq + ng;
-    const size_t arr_bytes = align_up(rows * Kp * sizeof(uint16_t), 256);
-    const size_t total = arr_bytes * (split ? 2 : 1) + align_up(rows * sizeof(float), 256);
-    char* ws = static_cast<char*>(workspace(ctx, total));
-    if (!ws) return DALI_ERR_NOMEM;
-    uint16_t* hi = reinterpret_cast<uint16_t*>(ws);
-    uint16_t* lo = split ? reinterpret_cast<uint16_t*>(ws + arr_bytes) : nullptr;
-    float* sq = reinterpret_cast<float*>(ws + arr_bytes * (split ? 2 : 1));
-    uint16_t* qhi = hi + (size_t)ng * Kp;
-    uint16_t* qlo = lo ? lo + (size_t)ng * Kp : nullptr;
-    int rc = dali_pairdist_prepare(ctx, stream, G, ng, d, normalize, hi, lo, sq);
+    uint16_t *g_img, *q_img;
+    float* sq;
+    const int rc = prepare_both(ctx, stream, Q, G, nq, ng, d, precision, normalize, g_img, q_img, sq);
     if (rc != DALI_OK) return rc;
-    rc = dali_pairdist_prepare(ctx, stream, Q, nq, d, normalize, qhi, qlo, sq + ng);
-    if (rc != DALI_OK) return rc;
-    return launch_pairdist((hipStream_t)stream, hi, lo, sq, qhi, qlo, sq + ng, nq, ng, Kp, DALI_METRIC_COSINE, split, inout,
+    return launch_pairdist((hipStream_t)stream, g_img, sq, q_img, sq + ng, nq, ng, d, DALI_METRIC_COSINE, precision == DALI_PREC_BF16X3, inout,
                            PairBlend{q_mag_prev, g_mag_prev, q_mag, g_mag, 1});
 }
 
