@@ -204,57 +204,69 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
 // a software-pipelined loop (wait + barrier half way through the k-step, next tile's first fragments fetched under the second
 // half of the MFMAs: the DMA lead shrinks from two k-steps to one, +5 % / +18 % time).
 template <int NPROD>
-__global__ __launch_bounds__(512) void pairdist_dma_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
-                                                           const float* __restrict__ gsq, const float* __restrict__ qsq,
-                                                           int ng, int nq, int pitch, int ktiles, int metric, float* out,
-                                                           int tiles_m, int tiles_n, PairBlend blend) {
+__global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
+                                                            const float* __restrict__ gsq, const float* __restrict__ qsq,
+                                                            int ng, int nq, int pitch, int ktiles, int metric, float* out,
+                                                            int tiles_m, int tiles_n, PairBlend blend) {
     constexpr int TM = 128, TN = 256;
     constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE = A_ELEMS + B_ELEMS;
-    constexpr int A_PIECES = TM / 8, NDMA = (TM + TN) / 8 / 8;                   // 1 KiB DMA pieces: 16 of A, 6 per wave
+    constexpr int A_PIECES = TM / 8, NDMA = (TM + TN) / 8 / 8;                   // 1 KiB DMA pieces: 16 of A, 6 per producer wave
+    static_assert(A_PIECES % 8 == 0, "a producer's piece i is a gallery piece for every producer or for none");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
     if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G), 0, ng * pitch * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Q), 0, nq * pitch * 2, 0x00020000);
-    // this wave's pieces: q = wave + 8*i; q < 16: rows 8q.. of the gallery tile, else rows 8(q-16).. of the query tile; both
-    // piece indices have the wave's parity, so one logical chunk per lane serves all of them
-    const int r_in = lane >> 3;
-    const int kc = (lane & 7) ^ (((wave & 1) << 2) | (r_in >> 1));
-    uint32_t off[NDMA];
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-        const int q = wave + 8 * i;
-        const bool is_a = q < A_PIECES;
-        const int row = is_a ? tm * TM + q * 8 + r_in : tn * TN + (q - A_PIECES) * 8 + r_in;
-        off[i] = (row < (is_a ? ng : nq)) ? (uint32_t)(row * pitch + kc * 8) * 2u : DMA_OOB;
-    }
-    static_assert(A_PIECES % 8 == 0, "a wave's piece i is a gallery piece for every wave or for none");
-    auto issue = [&](int kt, int stage) {
-        uint16_t* base = smem + stage * STAGE;
+    if (wave >= 8) {
+        // ---- producer waves 8..15 (two per SIMD, next to two consumers): nothing but the DMA ring ----
+        const int pw = wave - 8;
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G), 0, ng * pitch * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Q), 0, nq * pitch * 2, 0x00020000);
+        // pieces q = pw + 8*i; q < 16: rows 8q.. of the gallery tile, else rows 8(q-16).. of the query tile; both piece indices
+        // have the parity of pw, so one logical chunk per lane serves all of them
+        const int r_in = lane >> 3;
+        const int kc = (lane & 7) ^ (((pw & 1) << 2) | (r_in >> 1));
+        uint32_t off[NDMA];
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const uint32_t o = (off[i] == DMA_OOB) ? DMA_OOB : off[i] + (uint32_t)(kt * 128);
-            uint16_t* dst = base + (wave + 8 * i) * 512;
-            if (8 * i + 7 < A_PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_void_ptr)dst, 16, o, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)dst, 16, o, 0, 0, 0);
+            const int q = pw + 8 * i;
+            const bool is_a = q < A_PIECES;
+            const int row = is_a ? tm * TM + q * 8 + r_in : tn * TN + (q - A_PIECES) * 8 + r_in;
+            off[i] = (row < (is_a ? ng : nq)) ? (uint32_t)(row * pitch + kc * 8) * 2u : DMA_OOB;
         }
-    };
+        auto issue = [&](int kt, int stage) {
+            uint16_t* base = smem + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const uint32_t o = (off[i] == DMA_OOB) ? DMA_OOB : off[i] + (uint32_t)(kt * 128);
+                uint16_t* dst = base + (pw + 8 * i) * 512;
+                if (8 * i + 7 < A_PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_void_ptr)dst, 16, o, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)dst, 16, o, 0, 0, 0);
+            }
+        };
+        issue(0, 0);
+        if (ktiles > 1) { issue(1, 1); dma_wait<NDMA>(); } else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();                              // tile 0 visible
+        int st_fill = 2;
+        for (int kt = 0; kt < ktiles; ++kt) {
+            // the stage of tile kt+2 was last read in iteration kt-1, which every consumer left through the previous barrier
+            if (kt + 2 < ktiles) { issue(kt + 2, st_fill); dma_wait<NDMA>(); } else dma_wait<0>();     // tile kt+1 has landed
+            __builtin_amdgcn_s_barrier();
+            st_fill = (st_fill == 2) ? 0 : st_fill + 1;
+        }
+        return;
+    }
+    // ---- consumer waves 0..7: fragments + MFMAs only ----
+    const int wm = wave >> 2, wn = wave & 3;
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);   // first half; second half = ^ 32
-    issue(0, 0);
-    if (ktiles > 1) issue(1, 1);
-    if (ktiles > 1) dma_wait<NDMA>(); else dma_wait<0>();
     __builtin_amdgcn_s_barrier();
-    int st_cur = 0, st_fill = 2;
+    int st_cur = 0;
     for (int kt = 0; kt < ktiles; ++kt) {
-        if (kt + 2 < ktiles) issue(kt + 2, st_fill);
         const uint16_t* sa = smem + st_cur * STAGE;
         const uint16_t* sb = sa + A_ELEMS;
         bf16x8_t a0[4], a1[4];
@@ -278,10 +290,9 @@ __global__ __launch_bounds__(512) void pairdist_dma_kernel(const uint16_t* __res
                 }
             }
         }
-        if (kt + 2 < ktiles) dma_wait<NDMA>(); else dma_wait<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of this stage are complete before it can be refilled
         __builtin_amdgcn_s_barrier();
         st_cur = (st_cur == 2) ? 0 : st_cur + 1;
-        st_fill = (st_fill == 2) ? 0 : st_fill + 1;
     }
     pairdist_epilogue<4, 4>(acc, tm * TM, tn * TN, wm * 64 + (lane >> 4) * 4, wn * 64 + (lane & 15), gsq, qsq, ng, nq, metric, out, blend);
 }
@@ -510,8 +521,8 @@ static int launch_pairdist(hipStream_t st, const uint16_t* g_img, const float* g
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr_set = true;
         }
-        if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid2), dim3(512), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 32, metric, out, tm2, tn2, blend);
-        else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid2), dim3(512), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 64, metric, out, tm2, tn2, blend);
+        if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid2), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 32, metric, out, tm2, tn2, blend);
+        else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid2), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 64, metric, out, tm2, tn2, blend);
         DALI_LAUNCH_CHECK();
         return DALI_OK;
     }
