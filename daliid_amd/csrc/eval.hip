@@ -207,16 +207,20 @@ template <int NPROD>
 __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
                                                             const float* __restrict__ gsq, const float* __restrict__ qsq,
                                                             int ng, int nq, int pitch, int ktiles, int metric, float* out,
-                                                            int tiles_m, int tiles_n, PairBlend blend) {
+                                                            int tiles_m, int tiles_n, int vgrid, PairBlend blend) {
     constexpr int TM = 128, TN = 256;
     constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE = A_ELEMS + B_ELEMS;
     constexpr int A_PIECES = TM / 8, NDMA = (TM + TN) / 8 / 8;                   // 1 KiB DMA pieces: 16 of A, 6 per producer wave
     static_assert(A_PIECES % 8 == 0, "a producer's piece i is a gallery piece for every producer or for none");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    int tm, tn;
-    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Persistent: this workgroup owns the virtual blocks v = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so v
+    // stays on this XCD's share of the tile map); the k-steps of all its tiles form one stream through the 3-stage ring, so
+    // the producers fetch the next tile's first two k-steps while the consumers store the finished tile.
+    int n_tiles = 0;
+    for (int v = blockIdx.x; v < vgrid; v += gridDim.x) { int tm, tn; n_tiles += xcd_tile_map(v, tiles_m, tiles_n, tm, tn) ? 1 : 0; }
+    if (n_tiles == 0) return;
     if (wave >= 8) {
         // ---- producer waves 8..15 (two per SIMD, next to two consumers): nothing but the DMA ring ----
         const int pw = wave - 8;
@@ -227,74 +231,85 @@ __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __re
         const int r_in = lane >> 3;
         const int kc = (lane & 7) ^ (((pw & 1) << 2) | (r_in >> 1));
         uint32_t off[NDMA];
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int q = pw + 8 * i;
-            const bool is_a = q < A_PIECES;
-            const int row = is_a ? tm * TM + q * 8 + r_in : tn * TN + (q - A_PIECES) * 8 + r_in;
-            off[i] = (row < (is_a ? ng : nq)) ? (uint32_t)(row * pitch + kc * 8) * 2u : DMA_OOB;
-        }
-        auto issue = [&](int kt, int stage) {
-            uint16_t* base = smem + stage * STAGE;
+        int v_next = blockIdx.x, kt_next = 0, st_fill = 0;            // the step the next issue() fetches
+        auto seek_tile = [&]() {                                      // advance v_next to the next valid tile and load its row offsets
+            int tm = 0, tn = 0;
+            while (!xcd_tile_map(v_next, tiles_m, tiles_n, tm, tn)) v_next += gridDim.x;
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
-                const uint32_t o = (off[i] == DMA_OOB) ? DMA_OOB : off[i] + (uint32_t)(kt * 128);
+                const int q = pw + 8 * i;
+                const bool is_a = q < A_PIECES;
+                const int row = is_a ? tm * TM + q * 8 + r_in : tn * TN + (q - A_PIECES) * 8 + r_in;
+                off[i] = (row < (is_a ? ng : nq)) ? (uint32_t)(row * pitch + kc * 8) * 2u : DMA_OOB;
+            }
+        };
+        auto issue = [&]() {
+            if (kt_next == 0) seek_tile();
+            uint16_t* base = smem + st_fill * STAGE;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const uint32_t o = (off[i] == DMA_OOB) ? DMA_OOB : off[i] + (uint32_t)(kt_next * 128);
                 uint16_t* dst = base + (pw + 8 * i) * 512;
                 if (8 * i + 7 < A_PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_void_ptr)dst, 16, o, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)dst, 16, o, 0, 0, 0);
             }
-        };
-        issue(0, 0);
-        if (ktiles > 1) { issue(1, 1); dma_wait<NDMA>(); } else dma_wait<0>();
-        __builtin_amdgcn_s_barrier();                              // tile 0 visible
-        int st_fill = 2;
-        for (int kt = 0; kt < ktiles; ++kt) {
-            // the stage of tile kt+2 was last read in iteration kt-1, which every consumer left through the previous barrier
-            if (kt + 2 < ktiles) { issue(kt + 2, st_fill); dma_wait<NDMA>(); } else dma_wait<0>();     // tile kt+1 has landed
-            __builtin_amdgcn_s_barrier();
             st_fill = (st_fill == 2) ? 0 : st_fill + 1;
+            if (++kt_next == ktiles) { kt_next = 0; v_next += gridDim.x; }
+        };
+        const int steps = n_tiles * ktiles;
+        issue();
+        if (steps > 1) { issue(); dma_wait<NDMA>(); } else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();                              // step 0 visible
+        for (int s = 0; s < steps; ++s) {
+            // the stage of step s+2 was last read in step s-1, which every consumer left through the previous barrier
+            if (s + 2 < steps) { issue(); dma_wait<NDMA>(); } else dma_wait<0>();     // step s+1 has landed
+            __builtin_amdgcn_s_barrier();
         }
         return;
     }
-    // ---- consumer waves 0..7: fragments + MFMAs only ----
+    // ---- consumer waves 0..7: fragments + MFMAs + the tile's stores ----
     const int wm = wave >> 2, wn = wave & 3;
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);   // first half; second half = ^ 32
     __builtin_amdgcn_s_barrier();
     int st_cur = 0;
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const uint16_t* sa = smem + st_cur * STAGE;
-        const uint16_t* sb = sa + A_ELEMS;
-        bf16x8_t a0[4], a1[4];
+    for (int v = blockIdx.x; v < vgrid; v += gridDim.x) {
+        int tm, tn;
+        if (!xcd_tile_map(v, tiles_m, tiles_n, tm, tn)) continue;
+        f32x4_t acc[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a0[i] = *reinterpret_cast<const bf16x8_t*>(sa + (wm * 64 + i * 16) * 64 + frag_off);
-            a1[i] = *reinterpret_cast<const bf16x8_t*>(sa + (wm * 64 + i * 16) * 64 + (frag_off ^ 32));
-        }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(sb + (wn * 64 + j * 16) * 64 + frag_off);
-            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(sb + (wn * 64 + j * 16) * 64 + (frag_off ^ 32));
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const uint16_t* sa = smem + st_cur * STAGE;
+            const uint16_t* sb = sa + A_ELEMS;
+            bf16x8_t a0[4], a1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0, acc[i][j], 0, 0, 0);
-                if (NPROD == 3) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b1, acc[i][j], 0, 0, 0);       // hi . lo
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b0, acc[i][j], 0, 0, 0);       // lo . hi
-                } else {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1, acc[i][j], 0, 0, 0);       // next 32 k
+                a0[i] = *reinterpret_cast<const bf16x8_t*>(sa + (wm * 64 + i * 16) * 64 + frag_off);
+                a1[i] = *reinterpret_cast<const bf16x8_t*>(sa + (wm * 64 + i * 16) * 64 + (frag_off ^ 32));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(sb + (wn * 64 + j * 16) * 64 + frag_off);
+                const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(sb + (wn * 64 + j * 16) * 64 + (frag_off ^ 32));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0, acc[i][j], 0, 0, 0);
+                    if (NPROD == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b1, acc[i][j], 0, 0, 0);   // hi . lo
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b0, acc[i][j], 0, 0, 0);   // lo . hi
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1, acc[i][j], 0, 0, 0);   // next 32 k
+                    }
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of this stage are complete before it can be refilled
+            __builtin_amdgcn_s_barrier();
+            st_cur = (st_cur == 2) ? 0 : st_cur + 1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of this stage are complete before it can be refilled
-        __builtin_amdgcn_s_barrier();
-        st_cur = (st_cur == 2) ? 0 : st_cur + 1;
+        pairdist_epilogue<4, 4>(acc, tm * TM, tn * TN, wm * 64 + (lane >> 4) * 4, wn * 64 + (lane & 15), gsq, qsq, ng, nq, metric, out, blend);
     }
-    pairdist_epilogue<4, 4>(acc, tm * TM, tn * TN, wm * 64 + (lane >> 4) * 4, wn * 64 + (lane & 15), gsq, qsq, ng, nq, metric, out, blend);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,7 +522,7 @@ extern "C" int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x,
 static inline int pair_kp(int d, bool split) { return split ? (d + 31) & ~31 : (d + 63) & ~63; }
 static inline int pair_pitch(int d, bool split) { return split ? 2 * pair_kp(d, true) : pair_kp(d, false); }
 
-static int launch_pairdist(hipStream_t st, const uint16_t* g_img, const float* gsq, const uint16_t* q_img, const float* qsq, int nq, int ng,
+static int launch_pairdist(int num_cus, hipStream_t st, const uint16_t* g_img, const float* gsq, const uint16_t* q_img, const float* qsq, int nq, int ng,
                            int d, int metric, bool split, float* out, PairBlend blend = PairBlend{nullptr, nullptr, nullptr, nullptr, 0}) {
     static const bool no_dma = getenv("DALI_PAIRDIST_NODMA") != nullptr;
     const int Kp = pair_kp(d, split), pitch = pair_pitch(d, split);
@@ -521,8 +536,9 @@ static int launch_pairdist(hipStream_t st, const uint16_t* g_img, const float* g
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr_set = true;
         }
-        if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid2), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 32, metric, out, tm2, tn2, blend);
-        else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid2), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 64, metric, out, tm2, tn2, blend);
+        const int cap = num_cus / 8 * 8, grid = grid2 < cap ? grid2 : cap;          // persistent: one workgroup per CU (144 KiB of LDS each)
+        if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 32, metric, out, tm2, tn2, grid2, blend);
+        else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 64, metric, out, tm2, tn2, grid2, blend);
         DALI_LAUNCH_CHECK();
         return DALI_OK;
     }
@@ -568,7 +584,7 @@ extern "C" int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const void* q
     DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist_prepared: bad precision %d", precision);
     DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist_prepared: out must be 16-byte aligned");
     if (nq == 0 || ng == 0) return DALI_OK;
-    return launch_pairdist((hipStream_t)stream, static_cast<const uint16_t*>(g_image), g_sq, static_cast<const uint16_t*>(q_image), q_sq, nq, ng, d,
+    return launch_pairdist(ctx->num_cus, (hipStream_t)stream, static_cast<const uint16_t*>(g_image), g_sq, static_cast<const uint16_t*>(q_image), q_sq, nq, ng, d,
                            metric, precision == DALI_PREC_BF16X3, out);
 }
 
@@ -599,7 +615,7 @@ extern "C" int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const 
     float* sq;
     const int rc = prepare_both(ctx, stream, Q, G, nq, ng, d, precision, normalize, g_img, q_img, sq);
     if (rc != DALI_OK) return rc;
-    return launch_pairdist((hipStream_t)stream, g_img, sq, q_img, sq + ng, nq, ng, d, metric, precision == DALI_PREC_BF16X3, out);
+    return launch_pairdist(ctx->num_cus, (hipStream_t)stream, g_img, sq, q_img, sq + ng, nq, ng, d, metric, precision == DALI_PREC_BF16X3, out);
 }
 
 extern "C" int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
@@ -617,7 +633,7 @@ extern "C" int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, 
     float* sq;
     const int rc = prepare_both(ctx, stream, Q, G, nq, ng, d, precision, normalize, g_img, q_img, sq);
     if (rc != DALI_OK) return rc;
-    return launch_pairdist((hipStream_t)stream, g_img, sq, q_img, sq + ng, nq, ng, d, DALI_METRIC_COSINE, precision == DALI_PREC_BF16X3, inout,
+    return launch_pairdist(ctx->num_cus, (hipStream_t)stream, g_img, sq, q_img, sq + ng, nq, ng, d, DALI_METRIC_COSINE, precision == DALI_PREC_BF16X3, inout,
                            PairBlend{q_mag_prev, g_mag_prev, q_mag, g_mag, 1});
 }
 
