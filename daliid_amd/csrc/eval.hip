@@ -200,9 +200,17 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
 // no VGPR staging) into a [rows][64] LDS image (physical 16-byte chunk = logical ^ ((row >> 1) & 7), as the k-tile-64 conv
 // kernel); 48 KiB per stage, 3-stage ring with counted vmcnt.  Per k-step a wave reads 16 fragments for 48 (NPROD = 3: hi.hi +
 // hi.lo + lo.hi) or 32 MFMAs.
-// Measured and not kept: the two waves of a SIMD issuing their DMA pieces at different points of the k-step (no change), and
-// a software-pipelined loop (wait + barrier half way through the k-step, next tile's first fragments fetched under the second
-// half of the MFMAs: the DMA lead shrinks from two k-steps to one, +5 % / +18 % time).
+// Wave specialisation: waves 8..15 only issue the DMA pieces (60-185 issue cycles each; 6 per wave and k-step used to sit in
+// the MFMA waves' instruction streams and the feed time ADDED to the MFMA time: compute-only 0.89 us per k-step, with the feed
+// 1.17 us), waves 0..7 only read fragments and issue MFMAs: 1.03 us per k-step (bf16 x3), 0.45 -> 0.37 us (bf16).
+// Persistent: one workgroup per CU walks its tiles; the k-steps of all tiles form one stream through the ring, so the next
+// tile's first k-steps are fetched under the stores of the finished one.
+// Measured and not kept: the two waves of a SIMD issuing their DMA pieces at different points of the k-step (no change); a
+// software-pipelined loop (wait + barrier half way through the k-step, next tile's first fragments fetched under the second
+// half of the MFMAs: the DMA lead shrinks from two k-steps to one, +5 % / +18 % time); the tile staged through the free ring
+// stage and stored as 512-byte contiguous rows (the stores cost 8 of the 11 us a tile spends outside its k-loop, found by
+// removing them; staged they cost 6, but the kernel reaches the 128-VGPR cap, spills 15 registers around the k-loop and the
+// k-step slows by 10 %).
 template <int NPROD>
 __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
                                                             const float* __restrict__ gsq, const float* __restrict__ qsq,
