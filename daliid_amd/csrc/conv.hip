@@ -716,6 +716,129 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
     conv_epilogue_g<TM, TN, FM, FN, WN, NT>(a, acc, tm, tn, smem, wm, wn);
 }
 
+// Wave-specialised k-tile-64 kernel: WM x WN consumer waves (64 x 64 sub-tiles: fragment reads + MFMAs + epilogue) and NP
+// producer waves that do nothing but the gather arithmetic and the DMA pieces of the ring.  In the kernels above a DMA piece
+// costs the issuing wave 60-185 cycles in which it cannot issue MFMAs, and the feed time added to the MFMA time instead of
+// hiding under it (ablations in scripts/ablate_conv.py, same finding and same cure as pairdist_dma_kernel in eval.hip).
+// The producers leave after the last k-step; the epilogue's barriers then count the consumers only.
+template <int WM, int WN, int NP, int NSTAGE>
+__global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int TM = 64 * WM, TN = 64 * WN, NC = WM * WN, NT = NC * 64;
+    constexpr int A_BLK = TM / 8 / NP, B_BLK = TN / 8 / NP, NDMA = A_BLK + B_BLK;
+    constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE_ELEMS = A_ELEMS + B_ELEMS;
+    constexpr int AHEAD = NSTAGE - 1;
+    static_assert(NP % 2 == 0 && TM % (8 * NP) == 0 && TN % (8 * NP) == 0, "DMA pieces must divide evenly over an even number of producers");
+    static_assert(NSTAGE == 3, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    int tm, tn;
+    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const GatherGeom g = a.g;
+    const int ktiles = (g.nr * g.ns * g.Ck) >> 6;      // taps actually visited (all of them unless g.sub)
+    if (wave >= NC) {
+        // ---------------- producers ----------------
+        const int pw = wave - NC;
+        const int K = g.R * g.S * g.Ck;                // weight row length
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
+        const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+        const int r_in = lane >> 3;
+        const int kc = (lane & 7) ^ (((pw & 1) << 2) | (r_in >> 1));      // see igemm_conv_k64_kernel
+        uint32_t a_off[A_BLK];
+#pragma unroll
+        for (int i = 0; i < A_BLK; ++i) {
+            const int m = tm * TM + 8 * (pw + NP * i) + r_in;
+            a_off[i] = (m < a.Cm) ? (uint32_t)(m * K + kc * 8) * 2u : DMA_OOB;
+        }
+        int b_pix[B_BLK], b_h0[B_BLK], b_w0[B_BLK];
+#pragma unroll
+        for (int i = 0; i < B_BLK; ++i) {
+            const int p = tn * TN + 8 * (pw + NP * i) + r_in;
+            int n = 0, ho = 0, wo = 0;
+            const bool ok = p < a.P;
+            if (ok) decode_pixel(g, p, n, ho, wo);
+            if (g.sub) { ho = 2 * ho + g.oph; wo = 2 * wo + g.opw; }
+            if (g.mode == 0) { b_h0[i] = ho * g.stride - g.pad; b_w0[i] = wo * g.stride - g.pad; }
+            else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
+            if (!ok) b_h0[i] = -0x40000000;
+            b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;
+        }
+        int kr = g.r0, ks = g.s0, kc0 = 0;
+        const int ks_end = g.s0 + g.sstep * g.ns, kr_end = g.r0 + g.rstep * g.nr;
+        auto issue = [&](int stage) {
+            uint16_t* sa = smem + stage * STAGE_ELEMS;
+            uint16_t* sb = sa + A_ELEMS;
+            const int kbase = ((kr * g.S + ks) * g.Ck + kc0) * 2;
+#pragma unroll
+            for (int i = 0; i < A_BLK; ++i) {
+                const uint32_t off = (a_off[i] == DMA_OOB) ? DMA_OOB : a_off[i] + (uint32_t)kbase;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (pw + NP * i) * 512), 16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_BLK; ++i) {
+                int hi, wi;
+                bool ok = true;
+                if (g.mode == 0) { hi = b_h0[i] + kr; wi = b_w0[i] + ks; }
+                else {
+                    const int th = b_h0[i] - kr, tw = b_w0[i] - ks;
+                    ok = (th >= 0) && (tw >= 0);
+                    if (g.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                    else { hi = th; wi = tw; }
+                }
+                ok = ok && ((unsigned)hi < (unsigned)g.Hin) && ((unsigned)wi < (unsigned)g.Win);
+                const uint32_t off = ok ? (uint32_t)(b_pix[i] + hi * g.row_pitch + wi * g.pix_pitch + kc0) * 2u : DMA_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (pw + NP * i) * 512), 16, off, 0, 0, 0);
+            }
+            ks += g.sstep;                                   // taps fastest, channel block outermost (see igemm_conv_dma_kernel)
+            if (ks >= ks_end) { ks = g.s0; kr += g.rstep; if (kr >= kr_end) { kr = g.r0; kc0 += 64; } }
+        };
+        issue(0);
+        if (ktiles > 1) { issue(1); dma_wait<NDMA>(); } else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();                              // tile 0 visible
+        int st_fill = AHEAD % NSTAGE;
+        for (int kt = 0; kt < ktiles; ++kt) {
+            // the stage of tile kt+2 was last read in iteration kt-1, which every consumer left through the previous barrier
+            if (kt + AHEAD < ktiles) { issue(st_fill); dma_wait<NDMA>(); } else dma_wait<0>();      // tile kt+1 has landed
+            __builtin_amdgcn_s_barrier();
+            st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
+        }
+        return;
+    }
+    // ---------------- consumers ----------------
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);
+    const int a_row0 = wm * 64, b_row0 = wn * 64;
+    __builtin_amdgcn_s_barrier();
+    int st_cur = 0;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const uint16_t* sa = smem + st_cur * STAGE_ELEMS;
+        const uint16_t* sb = sa + A_ELEMS;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int fo = frag_off ^ (h << 5);
+            bf16x8_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + (a_row0 + i * 16) * 64 + fo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(sb + (b_row0 + j * 16) * 64 + fo);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of this stage are complete before it can be refilled
+        __builtin_amdgcn_s_barrier();
+        st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
+    }
+    conv_epilogue_g<TM, TN, 4, 4, WN, NT>(a, acc, tm, tn, smem, wm, wn);
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: M = Cm (channels of dY), N = R*S*Ck, K = pixels.  Both operands are stored pixel-major, so the
 // MFMA fragments (8 consecutive k per lane) are produced by ds_read_b64_tr_b16 transposing reads.
@@ -1448,7 +1571,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     // or the 128 x 128 tile the smaller k-tile's 2-3 co-resident workgroups overlap their epilogues better (measured per layer:
     // 256 x 256 -12..-15 %, 128 x 256 at Cm >= 256 -8..-14 %; Cm = 128 or K = 512: +15..+25 %)
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
-    if (k64 == 2 && !(K >= 1024 && (cfg == CONV_256x256 || (cfg == CONV_128x256 && a.Cm >= 256)))) k64 = 0;
+    if ((k64 == 2 || k64 == 6) && !(K >= 1024 && (cfg == CONV_256x256 || (cfg == CONV_128x256 && a.Cm >= 256)))) k64 = 0;
     if (k64 && cfg == CONV_256x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
@@ -1460,8 +1583,13 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
         const int lds = (128 + 256) * 64 * 2 * 3;
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
-        hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        if (k64 == 6) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
