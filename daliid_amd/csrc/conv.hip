@@ -721,14 +721,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
 // costs the issuing wave 60-185 cycles in which it cannot issue MFMAs, and the feed time added to the MFMA time instead of
 // hiding under it (ablations in scripts/ablate_conv.py, same finding and same cure as pairdist_dma_kernel in eval.hip).
 // The producers leave after the last k-step; the epilogue's barriers then count the consumers only.
-template <int WM, int WN, int NP, int NSTAGE>
+template <int WM, int WN, int NP, int NSTAGE, int FM = 4, int FN = 4>
 __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
-    constexpr int TM = 64 * WM, TN = 64 * WN, NC = WM * WN, NT = NC * 64;
+    constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NC = WM * WN, NT = NC * 64;       // consumer sub-tile 16 FM x 16 FN
     constexpr int A_BLK = TM / 8 / NP, B_BLK = TN / 8 / NP, NDMA = A_BLK + B_BLK;
     constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE_ELEMS = A_ELEMS + B_ELEMS;
     constexpr int AHEAD = NSTAGE - 1;
     static_assert(NP % 2 == 0 && TM % (8 * NP) == 0 && TN % (8 * NP) == 0, "DMA pieces must divide evenly over an even number of producers");
-    static_assert(NSTAGE == 3, "ring depth");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
     if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
@@ -794,12 +794,16 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
             if (ks >= ks_end) { ks = g.s0; kr += g.rstep; if (kr >= kr_end) { kr = g.r0; kc0 += 64; } }
         };
         issue(0);
-        if (ktiles > 1) { issue(1); dma_wait<NDMA>(); } else dma_wait<0>();
+        if constexpr (AHEAD == 2) { if (ktiles > 1) { issue(1); dma_wait<NDMA>(); } else dma_wait<0>(); }
+        else dma_wait<0>();
         __builtin_amdgcn_s_barrier();                              // tile 0 visible
         int st_fill = AHEAD % NSTAGE;
         for (int kt = 0; kt < ktiles; ++kt) {
-            // the stage of tile kt+2 was last read in iteration kt-1, which every consumer left through the previous barrier
-            if (kt + AHEAD < ktiles) { issue(st_fill); dma_wait<NDMA>(); } else dma_wait<0>();      // tile kt+1 has landed
+            // the stage of tile kt+AHEAD was last read in iteration kt-1, which every consumer left through the previous barrier
+            if (kt + AHEAD < ktiles) {
+                issue(st_fill);
+                if constexpr (AHEAD == 2) dma_wait<NDMA>(); else dma_wait<0>();                     // tile kt+1 has landed
+            } else dma_wait<0>();
             __builtin_amdgcn_s_barrier();
             st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
         }
@@ -807,13 +811,13 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
     }
     // ---------------- consumers ----------------
     const int wm = wave / WN, wn = wave % WN;
-    f32x4_t acc[4][4];
+    f32x4_t acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);
-    const int a_row0 = wm * 64, b_row0 = wn * 64;
+    const int a_row0 = wm * (16 * FM), b_row0 = wn * (16 * FN);
     __builtin_amdgcn_s_barrier();
     int st_cur = 0;
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -822,21 +826,21 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int fo = frag_off ^ (h << 5);
-            bf16x8_t fa[4];
+            bf16x8_t fa[FM];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + (a_row0 + i * 16) * 64 + fo);
+            for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + (a_row0 + i * 16) * 64 + fo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < FN; ++j) {
                 const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(sb + (b_row0 + j * 16) * 64 + fo);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of this stage are complete before it can be refilled
         __builtin_amdgcn_s_barrier();
         st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
     }
-    conv_epilogue_g<TM, TN, 4, 4, WN, NT>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1382,6 +1386,146 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs 
         }
 }
 
+// Wave-specialised variant of igemm_wgrad_wg_kernel: WM x WN consumer waves (transposing fragment reads + MFMAs + the slab
+// store) and NP producer waves (pixel decode, gather arithmetic, DMA pieces), see igemm_conv_k64s_kernel.  One workgroup per
+// CU (16 waves at <= 128 VGPRs), so the ring can be NSTAGE = 4 deep (3 k-steps in flight).
+template <int WM, int WN, int NP, int NSTAGE>
+__global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+    constexpr int TM = 64 * WM, TN = 64 * WN, NC = WM * WN;
+    constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128;
+    constexpr int NBLK = NIMG * 8 / NP;                 // 1 KiB DMA pieces per producer per k-step
+    constexpr int AHEAD = NSTAGE - 1;
+    static_assert((NIMG * 8) % NP == 0 && NP % 8 == 0 && TM % 128 == 0 && TN % 128 == 0, "unsupported wave grid");
+    static_assert(AHEAD >= 1 && AHEAD <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_m * tiles_n;
+    const int work = tiles * a.splits, per_xcd = (work + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= work) return;
+    const int ks = item / tiles, tile = item - ks * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const GatherGeom g = a.g;
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.P, p_begin + a.pix_per_split);
+    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+    if (wave >= NC) {
+        // ---------------- producers ----------------
+        if (ksteps == 0) return;
+        const int pw = wave - NC;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
+        const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+        // this producer's pieces: q = pw + NP*i -> image q>>3, piece q&7 (rows 4*(q&7) + lane>>4); (q&7) is the same for every i
+        const int r_in = lane >> 4, ps = lane & 15;
+        const int blk = pw & 7;
+        const int c16 = ((((ps >> 1) ^ wg_swz(4 * blk + r_in)) << 1) | (ps & 1));
+        bool is_a[NBLK], col_ok[NBLK];
+        int col[NBLK], tap_r[NBLK], tap_s[NBLK], img_of[NBLK];
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            const int q = pw + NP * i, img = q >> 3;
+            img_of[i] = img;
+            is_a[i] = img < NIMG_A;
+            if (is_a[i]) {
+                col[i] = m0 + img * 128 + c16 * 8;
+                col_ok[i] = col[i] < a.Cm;
+                tap_r[i] = tap_s[i] = 0;
+            } else {
+                const int bn = n0 + (img - NIMG_A) * 128 + c16 * 8;
+                col_ok[i] = bn < a.Ntot;
+                const int tap = col_ok[i] ? bn / g.Ck : 0;
+                col[i] = bn - tap * g.Ck;
+                tap_r[i] = tap / g.S; tap_s[i] = tap - tap_r[i] * g.S;
+            }
+        }
+        auto issue = [&](int kt, int stage) {
+            uint16_t* base = smem + stage * NIMG * IMG;
+            const int p = p_begin + kt * 32 + 4 * blk + r_in;
+            int n = 0, ho = 0, wo = 0;
+            const bool pok = p < p_end;
+            if (pok) decode_pixel(g, p, n, ho, wo);
+            const int pix_base = (int)((long long)n * g.img_pitch);
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                uint32_t off = DMA_OOB;
+                if (pok && col_ok[i]) {
+                    if (is_a[i]) off = (uint32_t)(p * a.Cm + col[i]) * 2u;
+                    else {
+                        const int hi = ho * g.stride - g.pad + tap_r[i], wi = wo * g.stride - g.pad + tap_s[i];
+                        if ((unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win)
+                            off = (uint32_t)(pix_base + hi * g.row_pitch + wi * g.pix_pitch + col[i]) * 2u;
+                    }
+                }
+                uint16_t* dst = base + img_of[i] * IMG + blk * 512;
+                if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+            }
+        };
+        auto wait_all_but = [&](int tiles_in_flight) {            // all but the youngest `tiles_in_flight` k-steps have landed
+            if (tiles_in_flight <= 0) dma_wait<0>();
+            else if (tiles_in_flight == 1) dma_wait<NBLK>();
+            else if (tiles_in_flight == 2) dma_wait<2 * NBLK>();
+            else dma_wait<3 * NBLK>();
+        };
+        int issued = 0;
+        for (; issued < AHEAD && issued < ksteps; ++issued) issue(issued, issued);
+        wait_all_but(issued - 1);
+        __builtin_amdgcn_s_barrier();                              // k-step 0 visible
+        int st_fill = AHEAD % NSTAGE;
+        for (int kt = 0; kt < ksteps; ++kt) {
+            // the stage of k-step kt+AHEAD was last read in iteration kt-1, which every consumer left through the previous barrier
+            if (kt + AHEAD < ksteps) issue(kt + AHEAD, st_fill);
+            const int left = ksteps - 1 - kt;
+            wait_all_but((left < AHEAD ? left : AHEAD) - 1);       // k-step kt+1 has landed
+            __builtin_amdgcn_s_barrier();
+            st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
+        }
+        return;
+    }
+    // ---------------- consumers ----------------
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (ksteps > 0) {
+        __builtin_amdgcn_s_barrier();
+        int st_cur = 0;
+        for (int kt = 0; kt < ksteps; ++kt) {
+            const uint16_t* sa = smem + st_cur * NIMG * IMG + (wm >> 1) * IMG;
+            const uint16_t* sb = smem + st_cur * NIMG * IMG + (NIMG_A + (wn >> 1)) * IMG;
+            bf16x8_t fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, (wm & 1) * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8_t fb = tr_frag(sb, (wn & 1) * 4 + j, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of this stage are complete before it can be refilled
+            __builtin_amdgcn_s_barrier();
+            st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
+        }
+    }
+    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
+                if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
+            }
+        }
+}
+
 // out[e] (= or +=) sum_s partial[s][e]; fixed summation tree => deterministic.  HBM-bound.
 // A block covers 256/SL float4 chunks; SL "split lanes" share the slabs of one chunk (s = lane, lane+SL, ...) and are
 // combined through LDS, so tiny outputs with hundreds of slabs (layer1's 64x64 weights) still use many threads.
@@ -1571,14 +1715,19 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     // or the 128 x 128 tile the smaller k-tile's 2-3 co-resident workgroups overlap their epilogues better (measured per layer:
     // 256 x 256 -12..-15 %, 128 x 256 at Cm >= 256 -8..-14 %; Cm = 128 or K = 512: +15..+25 %)
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
-    if ((k64 == 2 || k64 == 6) && !(K >= 1024 && (cfg == CONV_256x256 || (cfg == CONV_128x256 && a.Cm >= 256)))) k64 = 0;
+    if ((k64 == 2 || k64 == 6 || k64 == 7) && !(K >= 1024 && (cfg == CONV_256x256 || (cfg == CONV_128x256 && a.Cm >= 256)))) k64 = 0;
     if (k64 && cfg == CONV_256x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
         const int lds = (256 + 256) * 64 * 2 * 2;
         // (8 waves with 128 x 64 per wave, 25 % fewer LDS fragment bytes, 192 VGPRs: measured 3-5 % slower than 16 waves of 64 x 64)
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
-        hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 4, 2, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        if (k64 == 7) hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 4, 2, 8, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(768), lds, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
@@ -1645,6 +1794,12 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
 // 1 = 256 x 256 / 16 waves, 2 = 128 x 256 / 8 waves.  The wider tiles cut the L2 -> LDS operand bytes per FLOP and win
 // on the 1x1 layers with a long pixel (K) dimension; on 3x3 layers (each 128-column group of N is one tap's gather)
 // and on the ViT linears (25 k rows: the split-K slabs double) they lose.
+// DALI_WGRAD_SPEC=0 (A/B aid): the unspecialised 128 x 256 weight-gradient kernel, two workgroups per CU
+static int wgrad_spec() {
+    static int v = -1;
+    if (v == -1) { const char* e = getenv("DALI_WGRAD_SPEC"); v = e ? atoi(e) : 1; }
+    return v;
+}
 int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P, int halo_w) {
     static int ov = -2;
     if (ov == -2) { const char* e = getenv("DALI_WGRAD_CFG"); ov = e ? atoi(e) : -1; }
@@ -1661,7 +1816,7 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
     const int cfg = wgrad_pick_cfg(Cm, Ntot, taps, P, halo_w);
     const int TMc = cfg == 1 ? 256 : 128, TNc = cfg == 0 ? 128 : (cfg == 3 ? 9 * 64 : 256);
     if (cfg == 1 || cfg == 3) target_blocks = 256;  // one 16-wave / 8-wave block per CU
-    if (cfg == 2) target_blocks = 512;              // two 8-wave blocks per CU
+    if (cfg == 2) target_blocks = wgrad_spec() ? 256 : 512;     // one 16-wave (specialised) / two 8-wave blocks per CU
     const int tiles = ((Cm + TMc - 1) / TMc) * ((Ntot + TNc - 1) / TNc);
     int sp = (target_blocks + tiles - 1) / tiles;
     const int max_sp = (P + 255) / 256;              // at least 8 k-steps per block
@@ -1703,8 +1858,13 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
         static bool attr_set = false;
         const int tm2 = (a.Cm + 127) / 128, tn2 = (a.Ntot + 255) / 256;
         const int lds = 3 * 3 * 32 * 128 * 2;       // 3 stages x 3 images x 8 KiB
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
-        hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm2, tn2);
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
+            attr_set = true;
+        }
+        if (wgrad_spec()) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
+        else hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm2, tn2);
     } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
