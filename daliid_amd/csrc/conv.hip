@@ -1597,8 +1597,8 @@ static int conv_cfg_override() {
     if (v == -2) { const char* e = getenv("DALI_CONV_CFG"); v = e ? atoi(e) : -1; }
     return v;
 }
-// DALI_CONV_K64 (A/B aid): 0 = k-tile 32 kernels only, 2 (default) = k-tile 64 kernels on the long-K layers,
-// 4 / 3 = k-tile 64 wherever Ck % 64 == 0, the 128 x 128 tile with a 2- / 3-stage ring
+// DALI_CONV_K64 (A/B aid): 0 = k-tile 32 kernels only, 2 (default) = k-tile 64 kernels on the long-K layers, 6 = the same with
+// the unspecialised 128 x 256 kernel, 4 / 3 = k-tile 64 wherever Ck % 64 == 0, the 128 x 128 tile with a 2- / 3-stage ring
 static int conv_k64_mode() {
     static int v = -1;
     if (v == -1) { const char* e = getenv("DALI_CONV_K64"); v = e ? atoi(e) : 2; }
@@ -1711,23 +1711,20 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     }
     {
     ProfScope prof_scope(st, 0, 2.0 * a.Cm * (double)a.P * K);
-    // k-tile 64 pays where the main loop dominates (K >= 1024) and the tile leaves one workgroup per CU anyway; with a short K
-    // or the 128 x 128 tile the smaller k-tile's 2-3 co-resident workgroups overlap their epilogues better (measured per layer:
-    // 256 x 256 -12..-15 %, 128 x 256 at Cm >= 256 -8..-14 %; Cm = 128 or K = 512: +15..+25 %)
+    // k-tile 64 pays where the main loop dominates (K >= 1024); with a short K or the 128 x 128 tile the smaller k-tile's 2-3
+    // co-resident workgroups overlap their epilogues better (measured per layer: 256 x 256 -12..-15 %; 128 x 256 wave-specialised
+    // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
-    if ((k64 == 2 || k64 == 6 || k64 == 7) && !(K >= 1024 && (cfg == CONV_256x256 || (cfg == CONV_128x256 && a.Cm >= 256)))) k64 = 0;
+    if ((k64 == 2 || k64 == 6) && !(K >= 1024 && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
     if (k64 && cfg == CONV_256x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
         const int lds = (256 + 256) * 64 * 2 * 2;
         // (8 waves with 128 x 64 per wave, 25 % fewer LDS fragment bytes, 192 VGPRs: measured 3-5 % slower than 16 waves of 64 x 64)
-        if (!attr_set) {
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 4, 2, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
-        if (k64 == 7) hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 4, 2, 8, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(768), lds, st, args, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        // and the wave-specialised form (8 consumers of 128 x 64 + 4 producers, 168 VGPRs, 2-stage ring): -2 % on layer4's 3x3, +14 % on
+        // the stride-2 downsample dgrad -- a 256 x 256 tile has no room for producers beside 16 consumers (1024 threads per workgroup)
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
