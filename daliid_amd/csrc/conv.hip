@@ -1715,7 +1715,9 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     // co-resident workgroups overlap their epilogues better (measured per layer: 256 x 256 -12..-15 %; 128 x 256 wave-specialised
     // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
-    if ((k64 == 2 || k64 == 6) && !(K >= 1024 && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
+    static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
+    if (k64_min_k < 0) { const char* e = getenv("DALI_CONV_K64_MINK"); k64_min_k = e ? atoi(e) : 1024; }
+    if ((k64 == 2 || k64 == 6) && !(K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
     if (k64 && cfg == CONV_256x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
