@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_distance/ (from scripts/profile_distance.sh) -> profiles/r01_distance_kernel_stats.{md,csv}."""
+import csv, shutil
+src = "gpurun_out/prof_distance"
+shutil.copy(src + "/kernel_stats.csv", "profiles/r01_distance_kernel_stats.csv")
+last = lambda f: open(src + "/" + f).read().strip().splitlines()[-1]
+rows = list(csv.DictReader(open(src + "/kernel_stats.csv")))
+out = ["# Round 1 -- gallery distance (configs[4]) kernel profile\n",
+       "Produced by `bash scripts/profile_distance.sh` on an MI355X box: `python bench.py --workload distance --steps 5 --warmup 2` (unprofiled, with the CPU "
+       "baseline), the same with `--precision bf16`, `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload distance --steps 5 "
+       "--warmup 2 --no-cpu-baseline`, `python scripts/time_rank.py`; summary by `scripts/make_profile_distance_md.py`.\n",
+       "Bench line, unprofiled (bf16x3 = fp32-grade split-bf16):\n\n```\n%s\n```\n" % last("bench.json"),
+       "Bench line with `--precision bf16`:\n\n```\n%s\n```\n" % last("bench_bf16.json"),
+       "Bench line of the profiled run:\n\n```\n%s\n```\n" % last("bench_prof.json"),
+       "CMC/mAP kernel, worst case vs realistic ranking (`scripts/time_rank.py`; the kernel bins gallery entries only up to the last match, so "
+       "well-separated identities stop early):\n\n```\n%s\n```\n" % "\n".join(l[:160] for l in open(src + "/rank.txt").read().strip().splitlines() if "amdgpu.ids" not in l),
+       "Per-kernel summary of the profiled run (all launches of the process incl. warm-up):\n",
+       "| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|"]
+for r in rows[:12]:
+    out.append("| `%s` | %s | %.3f | %.1f | %.1f | %.1f | %.1f |" % (r["Name"][:100].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                                 float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["Percentage"])))
+open("profiles/r01_distance_kernel_stats.md", "w").write("\n".join(out) + "\n")
+print("wrote profiles/r01_distance_kernel_stats.md")
