@@ -27,6 +27,12 @@ CASES = [
     (2, 16, 8, 64, 64, 3, 3, 1, 1),       # layer1 conv2: halo wgrad kernel with a half-empty 128-channel co tile
     (3, 32, 32, 64, 128, 3, 3, 1, 1),     # halo wgrad, W = 32 (one image row per k-step), 3 images
     (2, 8, 16, 128, 192, 3, 3, 1, 1),     # halo wgrad, W = 16, Cout = 192 (1.5 co tiles)
+    # P >= 16384: the large-tile kernels (k-tile 64 / wave-specialised / 256 x 256) and the specialised weight gradient
+    (33, 32, 16, 256, 512, 3, 3, 1, 1),   # fwd 256x256 k-tile 64 (K = 2304); dgrad 128x256 specialised (K = 4608); halo wgrad
+    (33, 32, 16, 1024, 256, 1, 1, 1, 0),  # fwd 128x256 specialised (K = 1024); wgrad: specialised 128x256 kernel
+    (17, 31, 33, 1088, 320, 1, 1, 1, 0),  # ragged P = 17391, Cm = 320 (2.5 tiles), K = 17 x 64: specialised fwd + wgrad, zero-filled tails
+    (17, 31, 33, 1088, 576, 1, 1, 1, 0),  # ragged 256x256 k-tile 64 fwd (2.25 tiles); dgrad K = 576: k-tile 32 128x256 kernel
+    (128, 32, 16, 256, 256, 3, 3, 2, 1),  # layer3 conv2 (stride 2) at full pixel count: parity-split dgrad, its 4-tap class on the specialised kernel
 ]
 
 
