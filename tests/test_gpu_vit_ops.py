@@ -24,7 +24,9 @@ def close(got, ref, rel=2.0 ** -7, abs_frac=4e-3):
     assert (err <= tol).all(), "max err %.4g (ref scale %.4g)" % (float(err.max()), float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("rows,K,N", [(197 * 2, 768, 2304), (100, 3072, 768), (333, 768, 3072), (64, 64, 36)])
+# the last two: >= 16384 rows, i.e. the tiles and kernels the full-size model runs (256 x 256 k-tile 64 with the bias / GELU /
+# residual epilogue, wave-specialised 128 x 256, specialised weight gradient), ragged row count
+@pytest.mark.parametrize("rows,K,N", [(197 * 2, 768, 2304), (100, 3072, 768), (333, 768, 3072), (64, 64, 36), (16500, 3072, 768), (16500, 1024, 384)])
 def test_linear_fwd_dgrad_wgrad(V, rows, K, N):
     g = torch.Generator().manual_seed(rows + K + N)
     x = torch.randn(rows, K, generator=g).to(bf16)
