@@ -175,10 +175,12 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     static_assert(FN_ % 2 == 0, "the staged store splits the tile's pixels in two halves");
     const int lane = threadIdx.x & 63;
     const int mb = wm * (FM_ * 16) + (lane >> 4) * 4, nb = wn * (FN_ * 16) + (lane & 15);
+    // Precondition: the caller has synchronised after its main loop (every kernel ends the loop with a barrier that follows
+    // each wave's last fragment read), so smem is free.
     // ---- BatchNorm partial statistics: per channel sum / sumsq over this tile's pixels ----
+    constexpr int STAGE_BYTES = (TN / 2) * (TM * 2 + 32);      // the staged store's LDS image (below); the partial sums sit behind it
     if (a.stats) {
-        lds_barrier();                             // mainloop LDS reads are done: reuse smem
-        float* red = reinterpret_cast<float*>(smem);   // [WNW (wn)][TM][2]
+        float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + STAGE_BYTES);   // [WNW (wn)][TM][2]
 #pragma unroll
         for (int i = 0; i < Cfg::FM; ++i) {
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -205,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 *reinterpret_cast<float2*>(a.stats + ((size_t)tn * a.Cm + c) * 2) = make_float2(s1, s2);
             }
         }
-        lds_barrier();                             // the partial sums have been read: smem is free for the staged store
+        // no barrier: the staged store below does not touch `red`
     }
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 5] = __builtin_amdgcn_s_memrealtime();     // stats done
 
@@ -219,7 +221,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         char* stage = reinterpret_cast<char*>(smem);
         char* my_stage = stage + (wn * WROWS + (lane & 15)) * ROWB + mb * 2;              // + jj*16*ROWB + i*32
         const int ch = threadIdx.x % CPR, lp0 = threadIdx.x / CPR;                        // read-out: 16-byte chunk / first row
-        if (!a.stats) lds_barrier();
+        static_assert(ROWS * ROWB == STAGE_BYTES, "layout of the partial sums behind the staged tile");
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
