@@ -1717,6 +1717,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     // co-resident workgroups overlap their epilogues better (measured per layer: 256 x 256 -12..-15 %; 128 x 256 wave-specialised
     // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
+    const int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
     static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
     if (k64_min_k < 0) { const char* e = getenv("DALI_CONV_K64_MINK"); k64_min_k = e ? atoi(e) : 1024; }
     if ((k64 == 2 || k64 == 6) && !(K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
@@ -1750,6 +1751,15 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         }
         if (k64 == 3) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 2, st, args, tiles_m, tiles_n);
+    } else if (narrow_k64 == 2) {
+        // layer1's 3x3 (Cm = Cin = 64, K = 576): k-tile 64 = one full line per pixel and tap, 4 MFMA waves + 4 DMA waves, 2-stage ring,
+        // two workgroups per CU: 94 -> 77 us forward, 90 -> 73 us data gradient (unspecialised k-tile 64: 84 / 79; 3-stage ring, one
+        // workgroup per CU: 122 / 118)
+        static bool attr_set = false;
+        const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
+        const int lds = (64 + 256) * 64 * 2 * 2;
+        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
