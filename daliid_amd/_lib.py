@@ -37,7 +37,7 @@ _SIGNATURES = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_conv2d_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p],
     "dali_conv2d_stat_tiles": [c_int] * 10,
-    "dali_conv2d_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9,
+    "dali_conv2d_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9,
     "dali_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_int],
     "dali_bn_finalize": [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],

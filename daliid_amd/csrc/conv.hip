@@ -169,6 +169,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int FM_, int FN_> struct EpiShape { static constexpr int FM = FM_, FN = FN_; };
 // Generic over the block shape: TM x TN tile, WNW waves along n, NT threads; this wave sits at (wm, wn) and owns an
 // (FM*16) x (FN*16) sub-tile.
+// keep the bf16 halves of `w` whose mask bits (bit 0: low half, bit 1: high half) are set
+__device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, unsigned bits) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 0, 1) & 0xffffu;      // 0 or 0x0000ffff
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 1, 1) << 16;         // 0 or 0xffff0000
+    return w & (lo | hi);
+}
 template <int TM, int TN, int FM_, int FN_, int WNW, int NT>
 __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&acc)[FM_][FN_], int tm, int tn, uint16_t* smem, int wm, int wn) {
     using Cfg = EpiShape<FM_, FN_>;
@@ -230,8 +236,13 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 for (int it = 0; it < ITERS; ++it) {
                     const int lp = lp0 + it * (NT / CPR);
                     const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
-                    *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) =
-                        *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + gbase + (size_t)q * a.Cm * 2);
+                    const size_t rb = gbase + (size_t)q * a.Cm * 2;
+                    uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
+                    if (a.res_mask) {                           // 16 bytes = 8 channels = one mask byte
+                        const unsigned m = a.res_mask[rb >> 4];
+                        rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
+                    }
+                    *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) = rv;
                 }
                 lds_barrier_vm();                               // the loaded residual is visible to every wave
             }
@@ -294,7 +305,11 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                         v[t] *= 0.5f * (1.0f + erff(x4[t] * 0.70710678118654752f)) + x4[t] * 0.3989422804014327f * expf(-0.5f * x4[t] * x4[t]);
                 }
                 if (a.Res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(a.Res + o);
+                    uint2 rv = *reinterpret_cast<const uint2*>(a.Res + o);
+                    if (a.res_mask) {                           // o is a multiple of 4: this lane's nibble of the mask byte
+                        const unsigned m = a.res_mask[o >> 3] >> (o & 4);
+                        rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2);
+                    }
                     v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
                     v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
                 }
@@ -1963,14 +1978,15 @@ extern "C" int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int strid
 }
 
 extern "C" int dali_conv2d_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, uint16_t* dx,
-                                 const uint16_t* residual, int n, int h, int wd, int cin, int cout, int r, int s,
+                                 const uint16_t* residual, const uint8_t* residual_mask, int n, int h, int wd, int cin, int cout, int r, int s,
                                  int stride, int pad) {
     DALI_REQUIRE(ctx && dy && wt && dx, "dali_conv2d_dgrad: null argument");
+    DALI_REQUIRE(!residual_mask || (residual && cin % 8 == 0), "dali_conv2d_dgrad: residual_mask needs a residual and cin %% 8 == 0 (cin=%d)", cin);
     DALI_REQUIRE(cout % 32 == 0 && cin % 4 == 0, "dali_conv2d_dgrad: cout must be a multiple of 32 and cin of 4 (cin=%d cout=%d)", cin, cout);
     DALI_REQUIRE(stride == 1 || stride == 2, "dali_conv2d_dgrad: stride %d unsupported", stride);
     const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
     IGemmArgs a{};
-    a.W = wt; a.X = dy; a.O = dx; a.Res = residual; a.in_scale = nullptr; a.in_shift = nullptr; a.stats = nullptr;
+    a.W = wt; a.X = dy; a.O = dx; a.Res = residual; a.res_mask = residual_mask; a.in_scale = nullptr; a.in_shift = nullptr; a.stats = nullptr;
     a.Cm = cin; a.P = n * h * wd; a.in_relu = 0;
     fill_geom(a.g, n, ho, wo, cout, h, wd, r, s, stride, pad, 1);
     return launch_igemm_conv((hipStream_t)stream, a);

@@ -25,6 +25,8 @@ struct IGemmArgs {
     const uint16_t* X;        // gathered tensor
     uint16_t* O;              // [P][Cm]
     const uint16_t* Res;      // optional residual [P][Cm], added in the epilogue
+    const uint8_t* res_mask;  // optional 1-bit gate of Res (bit e & 7 of byte e >> 3, e = p*Cm + c): the ReLU mask of a block output,
+                              // so that dz = dy * (y > 0) is formed here instead of being written by the BatchNorm backward
     const float* in_scale;    // optional [Ck] affine (+ReLU) applied to X on load
     const float* in_shift;
     float* stats;             // optional [tiles_n][Cm][2] partial sum / sumsq of the fp32 results

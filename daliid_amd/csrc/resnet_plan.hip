@@ -366,9 +366,10 @@ int conv_wgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* 
     return launch_igemm_wgrad(st, a, net->G + c.w_off, 0);
 }
 
-int conv_dgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* dy, const uint16_t* residual, uint16_t* dx) {
+int conv_dgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* dy, const uint16_t* residual, uint16_t* dx,
+               const uint8_t* residual_mask = nullptr) {
     IGemmArgs a{};
-    a.W = c.wt_bf16; a.X = dy; a.O = dx; a.Res = residual; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.stats = nullptr;
+    a.W = c.wt_bf16; a.X = dy; a.O = dx; a.Res = residual; a.res_mask = residual_mask; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.stats = nullptr;
     a.Cm = c.cin; a.P = net->N * c.hin * c.win;
     a.g = conv_geom(c, 1);
     return launch_igemm_conv(st, a);
@@ -438,6 +439,12 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                            net->B + net->neck.rv_off, tr ? 1 : 0, 0.1f, 1e-5f, emb, net->neck_mean, net->neck_invstd);
 }
 
+// DALI_RESMASK=0 (A/B aid): the BatchNorm backward stores dz = dy * (y > 0) and conv1's data gradient adds it unmasked
+static bool res_mask_on() {
+    static int v = -1;
+    if (v == -1) { const char* e = getenv("DALI_RESMASK"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     int rc;
     uint16_t* dy = net->cur_dy;                                   // grad wrt block output y
@@ -446,15 +453,15 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
     uint16_t* d_rawd = b.has_ds ? next_gbuf(net, dy, d_raw3) : nullptr;
     BnBwdSide s3{b.raw3, b.b3.mean, b.b3.invstd, b.b3.scale, b.b3.shift};
     BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
-    // y = relu(bn3(raw3) + identity): dz = dy*(y>0) written in place over dy
+    // y = relu(bn3(raw3) + identity): dz = dy*(y>0) is not stored; the identity path's share is formed in conv1's data-gradient
+    // epilogue from dy and the block's 1-bit ReLU mask (one [P][cout] tensor write less per block without a downsample)
     rc = launch_bn_bwd(st, dy, nullptr, b.ybits, s3, b.has_ds ? &sd : nullptr, 1, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
                        net->G + b.b3.g_off, net->G + b.b3.b_off, b.has_ds ? net->G + b.bd.g_off : nullptr, b.has_ds ? net->G + b.bd.b_off : nullptr,
-                       d_raw3, d_rawd, b.has_ds ? nullptr : dy, net->red_scratch);   // dz only feeds the identity path (no downsample)
+                       d_raw3, d_rawd, (b.has_ds || res_mask_on()) ? nullptr : dy, net->red_scratch);
     if (rc) return rc;
-    uint16_t* dz = dy;
     // conv3
     if ((rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
-    uint16_t* d_a2 = next_gbuf(net, dz, d_raw3, d_rawd);
+    uint16_t* d_a2 = next_gbuf(net, dy, d_raw3, d_rawd);
     if ((rc = conv_dgrad(net, st, b.c3, d_raw3, nullptr, d_a2))) return rc;
     // bn2 + relu, in place.  The ReLU mask is recomputed from raw2 (raw*scale+shift > 0 <=> a2 > 0: bf16 rounding cannot
     // flush a positive fp32 to zero) instead of reading a2: one tensor read less in each of the two passes.
@@ -478,7 +485,7 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
         if ((rc = conv_dgrad(net, st, b.c1, d_a1, nullptr, dx))) return rc;
         if ((rc = conv_dgrad(net, st, b.cd, d_rawd, dx, dx))) return rc;
     } else {
-        if ((rc = conv_dgrad(net, st, b.c1, d_a1, dz, dx))) return rc;
+        if ((rc = conv_dgrad(net, st, b.c1, d_a1, dy, dx, res_mask_on() ? b.ybits : nullptr))) return rc;
     }
     net->cur_dy = dx;
     net->cur_dy_bytes = (int64_t)Pin * b.cin * 2;

@@ -29,9 +29,10 @@ def conv2d_fwd(x, w, stride=1, pad=0, in_scale=None, in_shift=None, in_relu=Fals
     return (y, stats) if want_stats else y
 
 
-def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, residual=None, inplace=False):
+def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, residual=None, inplace=False, residual_mask=None):
     """dy [N,Ho,Wo,Cout] bf16, wt [Cin,R,S,Cout] bf16 -> dx [N,H,W,Cin] bf16 (+ residual).  ``inplace``: accumulate into
-    ``residual`` itself (residual == dx; what the net plan does for the downsample branch)."""
+    ``residual`` itself (residual == dx; what the net plan does for the downsample branch).  ``residual_mask``: uint8
+    [N*H*W*Cin/8], 1 bit per residual element (``bn_act(..., want_mask=True)``): add the residual only where the bit is set."""
     n, ho, wo, cout = dy.shape
     cin, r, s, _ = wt.shape
     h, wd = x_hw
@@ -40,7 +41,8 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, residual=None, inplace=False):
         assert residual is not None and tuple(residual.shape) == (n, h, wd, cin) and residual.is_contiguous()
     dx = residual if inplace else torch.empty(n, h, wd, cin, device=dy.device, dtype=bf16)
     _lib.check(_lib.lib().dali_conv2d_dgrad(_lib.ctx(dy.device), _lib.stream_ptr(), _lib.ptr(dy, bf16, "dy"), _lib.ptr(wt, bf16, "wt"),
-                                             _lib.ptr(dx), _lib.ptr(residual), n, h, wd, cin, cout, r, s, stride, pad),
+                                             _lib.ptr(dx), _lib.ptr(residual), _lib.ptr(residual_mask, torch.uint8, "residual_mask"),
+                                             n, h, wd, cin, cout, r, s, stride, pad),
                "dali_conv2d_dgrad")
     return dx
 

@@ -122,9 +122,12 @@ int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16
                     const float* in_scale, const float* in_shift, int in_relu, float* stats);
 /* rows of the `stats` buffer for a given problem (depends on the tile configuration the launcher will pick). */
 int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int stride, int pad, int n, int ho, int wo, int fused_operand);
-/* dx[n,h,w,cin] = conv_transpose(dy, w) (+ residual[n,h,w,cin] if given).  cout % 32 == 0, cin % 4 == 0. */
+/* dx[n,h,w,cin] = conv_transpose(dy, w) (+ residual[n,h,w,cin] if given).  cout % 32 == 0, cin % 4 == 0.
+ * residual_mask (nullable; needs cin % 8 == 0): 1 bit per residual element, bit e & 7 of byte e >> 3 over the flat
+ * [n,h,w,cin] index, as dali_bn_act writes it for a block output: the residual is added only where the bit is set, i.e.
+ * the identity path's dy * (y > 0) of a bottleneck (Encoders.py:330-351 autograd) is formed here, not stored. */
 int dali_conv2d_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, uint16_t* dx,
-                      const uint16_t* residual, int n, int h, int wd, int cin, int cout, int r, int s,
+                      const uint16_t* residual, const uint8_t* residual_mask, int n, int h, int wd, int cin, int cout, int r, int s,
                       int stride, int pad);
 /* dw[cout][r][s][cin] (fp32) = (accumulate ? dw : 0) + sum_p dy[p][cout] * x_gathered[p][r,s,cin]; x may carry
  * the same fused affine(+ReLU) as the forward.  Deterministic split-K (fixed-order slab reduction). */

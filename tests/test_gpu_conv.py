@@ -83,6 +83,11 @@ def test_conv_fwd_dgrad_wgrad_exact_integers(nn, case):
         res = _ints((n, h, w, cin), gen)
         dxr = nn.conv2d_dgrad(dyg, w_dg, (h, w), stride, pad, residual=res.to(bf16).cuda())
         assert torch.equal(dxr.cpu(), (ref_dx + res).to(bf16))
+        # residual gated by a 1-bit mask (the identity path of a bottleneck: dy * (y > 0) formed in the epilogue)
+        bits = torch.randint(0, 2, (n, h, w, cin), generator=gen)
+        packed = (bits.reshape(-1, 8) << torch.arange(8)).sum(1).to(torch.uint8).cuda()
+        dxm = nn.conv2d_dgrad(dyg, w_dg, (h, w), stride, pad, residual=res.to(bf16).cuda(), residual_mask=packed)
+        assert torch.equal(dxm.cpu(), (ref_dx + res * bits).to(bf16))
         buf = res.to(bf16).cuda()                                            # accumulate in place (residual == dx)
         dxi = nn.conv2d_dgrad(dyg, w_dg, (h, w), stride, pad, residual=buf, inplace=True)
         assert dxi.data_ptr() == buf.data_ptr() and torch.equal(dxi.cpu(), (ref_dx + res).to(bf16))
