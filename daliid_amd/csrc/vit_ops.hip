@@ -264,7 +264,7 @@ __global__ void finish_sum_kernel(const double* __restrict__ scratch, int S, int
 // LDS images are plain row-major [Tp][72] bf16 (64 + 8 pad): both the K-contiguous (ds_read_b128) and the transposing
 // (tr_b16) fragment reads work on it.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_TP = 208, ATT_LD = 72, ATT_PK = 224, ATT_HD = 64;
+constexpr int ATT_TP = 208, ATT_LD = 72, ATT_PK = 224, ATT_HD = 64, ATT_FWD_NW = 8;
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef short s16x8v __attribute__((ext_vector_type(8)));
 
@@ -285,7 +285,7 @@ __device__ __forceinline__ bf16x8_t frag_tr(const uint16_t* base, int ld, int k0
 
 __device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, size_t row_stride, int T, uint16_t* dst) {
     // [T][64] bf16 from global (row stride in elements) -> LDS [ATT_TP][ATT_LD], rows >= T zeroed
-    for (int i = threadIdx.x; i < ATT_TP * 8; i += 256) {
+    for (int i = threadIdx.x; i < ATT_TP * 8; i += blockDim.x) {
         const int row = i >> 3, ch = i & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < T) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
@@ -293,7 +293,9 @@ __device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, 
     }
 }
 
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
+// ATT_FWD_NW waves per (batch, head): 13 query tiles over 8 waves = 2 rounds (4 waves: 4 rounds, 134 -> see profiles); the 8 P strips
+// still fit beside Q, K, V (150 KiB)
+__global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
                                                              uint16_t* __restrict__ out, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     uint16_t* sQ = sm;
@@ -307,11 +309,11 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const uint16_t* __re
     att_load_tile(base, rs, T, sQ);
     att_load_tile(base + C, rs, T, sK);
     att_load_tile(base + 2 * C, rs, T, sV);
-    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += 256) sV[ATT_TP * ATT_LD + i] = 0;
+    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += ATT_FWD_NW * 64) sV[ATT_TP * ATT_LD + i] = 0;
     __syncthreads();
     uint16_t* myP = sP + wave * 16 * ATT_PK;
     for (int i = lane; i < 16 * (ATT_PK - ATT_TP); i += 64) myP[(i / 16) * ATT_PK + ATT_TP + (i & 15)] = 0;   // pad columns stay 0
-    for (int qt = wave; qt < ATT_TP / 16; qt += 4) {
+    for (int qt = wave; qt < ATT_TP / 16; qt += ATT_FWD_NW) {
         if (qt * 16 >= T) break;
         const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
         // Score tiles are computed TRANSPOSED (rows = keys, columns = this tile's 16 queries): a lane owns ONE query (lane&15)
@@ -572,11 +574,11 @@ int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-constexpr size_t ATT_FWD_LDS = ((size_t)2 * ATT_TP * ATT_LD + (size_t)ATT_PK * ATT_LD + 4 * 16 * ATT_PK) * 2;
+constexpr size_t ATT_FWD_LDS = ((size_t)2 * ATT_TP * ATT_LD + (size_t)ATT_PK * ATT_LD + ATT_FWD_NW * 16 * ATT_PK) * 2;
 constexpr size_t ATT_BWD_LDS = ((size_t)4 * ATT_PK * ATT_LD + 4 * 16 * ATT_PK) * 2 + 2 * ATT_PK * 4;
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
     DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_FWD_LDS));
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), ATT_FWD_LDS, st, qkv, B, T, H, scale, out, lse);
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(ATT_FWD_NW * 64), ATT_FWD_LDS, st, qkv, B, T, H, scale, out, lse);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
