@@ -371,16 +371,21 @@ __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const ui
 // D_i = rowsum(dO * O); dS = P * (dP - D_i) * scale; dQ = dS K (K through the transposing read).  dS and P strips are kept
 // nowhere: pass B (a wave owns 16 keys) recomputes S^T = K Q^T, P^T, dP^T = V dO^T and forms dK = dS^T Q, dV = P^T dO
 // with Q / dO consumed through the transposing read.  No cross-block reduction, no atomics.
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
-                                                             const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                             int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
+// 8 waves per (batch, head): 13 query / key tiles in 2 rounds instead of 4.  Four [224][72] images leave 32 KiB for the strips,
+// so a wave's strip holds HALF of the keys (queries) at a time: [16][128] bf16, tiles 0..7 then tiles 8..12 (+ one zero tile),
+// each half followed by its share of the second GEMM (4 resp. 3 k-steps of 32).
+constexpr int ATT_BWD_NW = 8, ATT_SW = 128;
+__global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                                        const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                                        int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
+    constexpr int NT = ATT_BWD_NW * 64, NTILE = ATT_TP / 16;       // 13 tiles of 16
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     uint16_t* sQ = sm;
     uint16_t* sK = sQ + ATT_PK * ATT_LD;
     uint16_t* sV = sK + ATT_PK * ATT_LD;
     uint16_t* sD = sV + ATT_PK * ATT_LD;                           // dO
-    uint16_t* sP = sD + ATT_PK * ATT_LD;                           // per-wave strips [4][16][224]
-    float* sLse = reinterpret_cast<float*>(sP + 4 * 16 * ATT_PK);  // [224]
+    uint16_t* sP = sD + ATT_PK * ATT_LD;                           // per-wave strips [NW][16][128]
+    float* sLse = reinterpret_cast<float*>(sP + ATT_BWD_NW * 16 * ATT_SW);  // [224]
     float* sDi = sLse + ATT_PK;                                    // [224]
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -390,11 +395,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __re
     att_load_tile(base + C, rs, T, sK);
     att_load_tile(base + 2 * C, rs, T, sV);
     att_load_tile(d_o + (size_t)b * T * C + h * ATT_HD, C, T, sD);
-    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += 256) {
+    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += NT) {
         sQ[ATT_TP * ATT_LD + i] = 0; sK[ATT_TP * ATT_LD + i] = 0; sV[ATT_TP * ATT_LD + i] = 0; sD[ATT_TP * ATT_LD + i] = 0;
     }
     // D_i = sum_d dO[i][d] * O[i][d] (8 lanes x 16 bytes per row, coalesced; reduced over the 8 lanes); lse
-    for (int i0 = 0; i0 < ATT_PK; i0 += 32) {
+    for (int i0 = 0; i0 < ATT_PK; i0 += NT / 8) {
         const int i = i0 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
         float acc = 0.f;
         if (i < T) {
@@ -407,41 +412,48 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __re
         acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
         if (ch == 0 && i < ATT_PK) sDi[i] = acc;
     }
-    for (int i = threadIdx.x; i < ATT_PK; i += 256) sLse[i] = (i < T) ? lse[(size_t)bh * T + i] : 0.f;
+    for (int i = threadIdx.x; i < ATT_PK; i += NT) sLse[i] = (i < T) ? lse[(size_t)bh * T + i] : 0.f;
     __syncthreads();
-    uint16_t* myP = sP + wave * 16 * ATT_PK;
-    for (int i = lane; i < 16 * (ATT_PK - ATT_TP); i += 64) myP[(i / 16) * ATT_PK + ATT_TP + (i & 15)] = 0;
+    uint16_t* myP = sP + wave * 16 * ATT_SW;
     uint16_t* dq_base = dqkv + (size_t)b * T * rs + h * ATT_HD;
+    const float sc2 = scale * 1.44269504088896f;
     // ---- pass A: dQ ----
-    for (int qt = wave; qt < ATT_TP / 16; qt += 4) {
+    for (int qt = wave; qt < NTILE; qt += ATT_BWD_NW) {
         if (qt * 16 >= T) break;
         const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
         const bf16x8_t ga0 = frag_k(sD, ATT_LD, qt * 16, 0, lane), ga1 = frag_k(sD, ATT_LD, qt * 16, 32, lane);
         // score tiles are computed TRANSPOSED (rows = keys, columns = this tile's queries): a lane then holds 4 consecutive
         // keys of one query = one 8-byte write into the [query][key] strip (the un-transposed form needed four 2-byte writes)
-        const float lq = sLse[qt * 16 + (lane & 15)] * 1.44269504088896f, dq_i = sDi[qt * 16 + (lane & 15)], sc2 = scale * 1.44269504088896f;
-#pragma unroll
-        for (int j = 0; j < ATT_TP / 16; ++j) {
-            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 0, lane), ga0, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 32, lane), ga1, dp, 0, 0, 0);
-            const int key0 = j * 16 + (lane >> 4) * 4;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = (key0 + r < T) ? __builtin_amdgcn_exp2f(s[r] * sc2 - lq) : 0.f;
-                v[r] = p * (dp[r] - dq_i) * scale;
-            }
-            *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_PK + key0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        }
+        const float lq = sLse[qt * 16 + (lane & 15)] * 1.44269504088896f, dq_i = sDi[qt * 16 + (lane & 15)];
         f32x4_t dq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int kk = 0; kk < ATT_PK / 32; ++kk) {
-            const bf16x8_t da = frag_k(myP, ATT_PK, 0, kk * 32, lane);
+        for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, frag_tr(sK, ATT_LD, kk * 32, d * 16, lane), dq[d], 0, 0, 0);
+            for (int jj = 0; jj < (hf == 0 ? 8 : 6); ++jj) {        // second half: tiles 8..12 and one zero tile (keys 208..223)
+                const int j = hf * 8 + jj;
+                const int key0 = j * 16 + (lane >> 4) * 4;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (j < NTILE) {
+                    f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, sc, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 0, lane), ga0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 32, lane), ga1, dp, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = (key0 + r < T) ? __builtin_amdgcn_exp2f(sc[r] * sc2 - lq) : 0.f;
+                        v[r] = p * (dp[r] - dq_i) * scale;
+                    }
+                }
+                *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+#pragma unroll
+            for (int kk = 0; kk < (hf == 0 ? 4 : 3); ++kk) {
+                const bf16x8_t da = frag_k(myP, ATT_SW, 0, kk * 32, lane);
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, frag_tr(sK, ATT_LD, hf * 128 + kk * 32, d * 16, lane), dq[d], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -452,44 +464,50 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const uint16_t* __re
             }
     }
     // ---- pass B: dK, dV (rows = keys, columns = queries) ----
-    for (int kt = wave; kt < ATT_TP / 16; kt += 4) {
+    for (int kt = wave; kt < NTILE; kt += ATT_BWD_NW) {
         if (kt * 16 >= T) break;
         const bf16x8_t ka0 = frag_k(sK, ATT_LD, kt * 16, 0, lane), ka1 = frag_k(sK, ATT_LD, kt * 16, 32, lane);
         const bf16x8_t va0 = frag_k(sV, ATT_LD, kt * 16, 0, lane), va1 = frag_k(sV, ATT_LD, kt * 16, 32, lane);
         f32x4_t dk[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x4_t dv[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        // P^T strip first (for dV), then overwritten by dS^T (for dK): two sweeps over the queries
+        const bool key_ok = kt * 16 + (lane & 15) < T;
+        // P^T strip first (for dV), then dS^T (for dK): two sweeps over the queries, each in two halves
         for (int sweep = 0; sweep < 2; ++sweep) {
 #pragma unroll
-            for (int j = 0; j < ATT_TP / 16; ++j) {                 // query tile j
-                // rows = queries of tile j, columns = this tile's keys: 4 consecutive queries of one key per lane = one
-                // 8-byte write into the [key][query] strip
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 0, lane), ka0, st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 32, lane), ka1, st, 0, 0, 0);
-                if (sweep == 1) {
-                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 0, lane), va0, dpt, 0, 0, 0);
-                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 32, lane), va1, dpt, 0, 0, 0);
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int jj = 0; jj < (hf == 0 ? 8 : 6); ++jj) {    // query tile j = 8 hf + jj
+                    const int j = hf * 8 + jj;
+                    const int q0 = j * 16 + (lane >> 4) * 4;       // first of this lane's 4 queries
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (j < NTILE) {
+                        // rows = queries of tile j, columns = this tile's keys: 4 consecutive queries of one key per lane = one
+                        // 8-byte write into the [key][query] strip
+                        f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+                        st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 0, lane), ka0, st, 0, 0, 0);
+                        st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 32, lane), ka1, st, 0, 0, 0);
+                        if (sweep == 1) {
+                            dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 0, lane), va0, dpt, 0, 0, 0);
+                            dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 32, lane), va1, dpt, 0, 0, 0);
+                        }
+                        const float4 lq4 = *reinterpret_cast<const float4*>(sLse + q0), dq4 = *reinterpret_cast<const float4*>(sDi + q0);
+                        const float lqv[4] = {lq4.x, lq4.y, lq4.z, lq4.w}, dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = (key_ok && q0 + r < T) ? __builtin_amdgcn_exp2f((st[r] * scale - lqv[r]) * 1.44269504088896f) : 0.f;
+                            v[r] = sweep == 0 ? p : p * (dpt[r] - dqv[r]) * scale;
+                        }
+                    }
+                    *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
-                const int q0 = j * 16 + (lane >> 4) * 4;           // first of this lane's 4 queries
-                const bool key_ok = kt * 16 + (lane & 15) < T;
-                const float4 lq4 = *reinterpret_cast<const float4*>(sLse + q0), dq4 = *reinterpret_cast<const float4*>(sDi + q0);
-                const float lqv[4] = {lq4.x, lq4.y, lq4.z, lq4.w}, dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
-                float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = (key_ok && q0 + r < T) ? __builtin_amdgcn_exp2f((st[r] * scale - lqv[r]) * 1.44269504088896f) : 0.f;
-                    v[r] = sweep == 0 ? p : p * (dpt[r] - dqv[r]) * scale;
-                }
-                *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_PK + q0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
+                for (int kk = 0; kk < (hf == 0 ? 4 : 3); ++kk) {
+                    const bf16x8_t a = frag_k(myP, ATT_SW, 0, kk * 32, lane);
 #pragma unroll
-            for (int kk = 0; kk < ATT_PK / 32; ++kk) {
-                const bf16x8_t a = frag_k(myP, ATT_PK, 0, kk * 32, lane);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (sweep == 0) dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sD, ATT_LD, kk * 32, d * 16, lane), dv[d], 0, 0, 0);
-                    else dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sQ, ATT_LD, kk * 32, d * 16, lane), dk[d], 0, 0, 0);
+                    for (int d = 0; d < 4; ++d) {
+                        if (sweep == 0) dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sD, ATT_LD, hf * 128 + kk * 32, d * 16, lane), dv[d], 0, 0, 0);
+                        else dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sQ, ATT_LD, hf * 128 + kk * 32, d * 16, lane), dk[d], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -575,7 +593,7 @@ int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out
     return DALI_OK;
 }
 constexpr size_t ATT_FWD_LDS = ((size_t)2 * ATT_TP * ATT_LD + (size_t)ATT_PK * ATT_LD + ATT_FWD_NW * 16 * ATT_PK) * 2;
-constexpr size_t ATT_BWD_LDS = ((size_t)4 * ATT_PK * ATT_LD + 4 * 16 * ATT_PK) * 2 + 2 * ATT_PK * 4;
+constexpr size_t ATT_BWD_LDS = ((size_t)4 * ATT_PK * ATT_LD + ATT_BWD_NW * 16 * ATT_SW) * 2 + 2 * ATT_PK * 4;
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
     DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_FWD_LDS));
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(ATT_FWD_NW * 64), ATT_FWD_LDS, st, qkv, B, T, H, scale, out, lse);
@@ -585,7 +603,7 @@ int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int 
 int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
                          float scale, uint16_t* dqkv) {
     DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_BWD_LDS));
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), ATT_BWD_LDS, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(ATT_BWD_NW * 64), ATT_BWD_LDS, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
