@@ -264,7 +264,7 @@ __global__ void finish_sum_kernel(const double* __restrict__ scratch, int S, int
 // LDS images are plain row-major [Tp][72] bf16 (64 + 8 pad): both the K-contiguous (ds_read_b128) and the transposing
 // (tr_b16) fragment reads work on it.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_TP = 208, ATT_LD = 72, ATT_PK = 224, ATT_HD = 64, ATT_FWD_NW = 8;
+constexpr int ATT_TP = 208, ATT_LD = 72, ATT_PK = 224, ATT_HD = 64, ATT_FWD_NW = 13, ATT_SW = 128;   // ATT_SW: columns of a half strip
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef short s16x8v __attribute__((ext_vector_type(8)));
 
@@ -293,8 +293,8 @@ __device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, 
     }
 }
 
-// ATT_FWD_NW waves per (batch, head): 13 query tiles over 8 waves = 2 rounds (4 waves: 4 rounds, 134 -> see profiles); the 8 P strips
-// still fit beside Q, K, V (150 KiB)
+// ATT_FWD_NW = 13 waves per (batch, head): one query tile per wave (4 waves: 4 rounds, 134 us per layer; 8 waves: 89 us).  A wave's P
+// strip holds half of the keys at a time ([16][128] bf16: tiles 0..7, then tiles 8..12 + one zero tile), so 13 strips fit beside Q, K, V.
 __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
                                                              uint16_t* __restrict__ out, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
@@ -311,8 +311,7 @@ __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const ui
     att_load_tile(base + 2 * C, rs, T, sV);
     for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += ATT_FWD_NW * 64) sV[ATT_TP * ATT_LD + i] = 0;
     __syncthreads();
-    uint16_t* myP = sP + wave * 16 * ATT_PK;
-    for (int i = lane; i < 16 * (ATT_PK - ATT_TP); i += 64) myP[(i / 16) * ATT_PK + ATT_TP + (i & 15)] = 0;   // pad columns stay 0
+    uint16_t* myP = sP + wave * 16 * ATT_SW;
     for (int qt = wave; qt < ATT_TP / 16; qt += ATT_FWD_NW) {
         if (qt * 16 >= T) break;
         const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
@@ -340,22 +339,28 @@ __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const ui
             for (int r = 0; r < 4; ++r) { s[j][r] = __builtin_amdgcn_exp2f(s[j][r] - m); l += s[j][r]; }
         l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
         const float inv_l = 1.0f / l;
-        // P -> per-wave LDS strip [16 queries][224 keys] bf16
-#pragma unroll
-        for (int j = 0; j < ATT_TP / 16; ++j)
-            *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_PK + j * 16 + (lane >> 4) * 4) =
-                make_uint2(pack_bf16x2(s[j][0] * inv_l, s[j][1] * inv_l), pack_bf16x2(s[j][2] * inv_l, s[j][3] * inv_l));
         if (lane < 16) {
             const int row = qt * 16 + lane;
             if (row < T && lse) lse[(size_t)bh * T + row] = (m + log2f(l)) * 0.6931471805599453f;     // natural-log lse = max + log(sum)
         }
-        // O = P V : A = P (k = key, contiguous), B[k = key][n = d] = V[key][d] through the transposing read
+        // O = P V : A = P (k = key, contiguous) from the per-wave strip, B[k = key][n = d] = V[key][d] through the transposing read
         f32x4_t o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int kk = 0; kk < ATT_PK / 32; ++kk) {
-            const bf16x8_t pa = frag_k(myP, ATT_PK, 0, kk * 32, lane);
+        for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(sV, ATT_LD, kk * 32, d * 16, lane), o[d], 0, 0, 0);
+            for (int jj = 0; jj < (hf == 0 ? 8 : 6); ++jj) {
+                const int j = hf * 8 + jj;
+                uint2 pv = make_uint2(0u, 0u);
+                if (j < ATT_TP / 16) pv = make_uint2(pack_bf16x2(s[j < ATT_TP / 16 ? j : 0][0] * inv_l, s[j < ATT_TP / 16 ? j : 0][1] * inv_l),
+                                                      pack_bf16x2(s[j < ATT_TP / 16 ? j : 0][2] * inv_l, s[j < ATT_TP / 16 ? j : 0][3] * inv_l));
+                *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = pv;
+            }
+#pragma unroll
+            for (int kk = 0; kk < (hf == 0 ? 4 : 3); ++kk) {
+                const bf16x8_t pa = frag_k(myP, ATT_SW, 0, kk * 32, lane);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(sV, ATT_LD, hf * 128 + kk * 32, d * 16, lane), o[d], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const ui
 // 8 waves per (batch, head): 13 query / key tiles in 2 rounds instead of 4.  Four [224][72] images leave 32 KiB for the strips,
 // so a wave's strip holds HALF of the keys (queries) at a time: [16][128] bf16, tiles 0..7 then tiles 8..12 (+ one zero tile),
 // each half followed by its share of the second GEMM (4 resp. 3 k-steps of 32).
-constexpr int ATT_BWD_NW = 8, ATT_SW = 128;
+constexpr int ATT_BWD_NW = 8;
 __global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                                         const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                         int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
@@ -592,7 +597,7 @@ int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-constexpr size_t ATT_FWD_LDS = ((size_t)2 * ATT_TP * ATT_LD + (size_t)ATT_PK * ATT_LD + ATT_FWD_NW * 16 * ATT_PK) * 2;
+constexpr size_t ATT_FWD_LDS = ((size_t)2 * ATT_TP * ATT_LD + (size_t)ATT_PK * ATT_LD + ATT_FWD_NW * 16 * ATT_SW) * 2;
 constexpr size_t ATT_BWD_LDS = ((size_t)4 * ATT_PK * ATT_LD + ATT_BWD_NW * 16 * ATT_SW) * 2 + 2 * ATT_PK * 4;
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
     DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_FWD_LDS));
