@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const uint16_t* __re
 
 // dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat)) (+ add);  per-block partials of
 // dgamma = sum_rows g*xhat and dbeta = sum_rows g   ->  partial[block][C][2]
+// NCH = 16-byte chunks per lane (C <= 512 NCH): the per-lane arrays are sized for the actual width (ViT-B: 2), not for the 2048 maximum
+// (160 of ~200 VGPRs were dead weight and held the kernel to 2 waves per SIMD)
+template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const uint16_t* __restrict__ add,
@@ -142,18 +145,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                                                              float* __restrict__ partial, const float* __restrict__ g32) {
     extern __shared__ float red[];                                  // [4 waves][C][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[LN_MAXCH][8], db[LN_MAXCH][8];
+    float dg[NCH][8], db[NCH][8];
 #pragma unroll
-    for (int k = 0; k < LN_MAXCH; ++k)
+    for (int k = 0; k < NCH; ++k)
 #pragma unroll
         for (int t = 0; t < 8; ++t) { dg[k][t] = 0.f; db[k][t] = 0.f; }
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float gam[NCH][8];                                        // this lane's gamma values: loaded once, not per row
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = (lane + k * 64) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) gam[k][t] = (c < C) ? gamma[c + t] : 0.f;
+    }
     for (int row = r0 + wave; row < r1; row += 4) {
         const float mu = mean[row], rs = rstd[row];
-        float gv[LN_MAXCH][8], xh[LN_MAXCH][8];
+        float gv[NCH][8], xh[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXCH; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int c = (lane + k * 64) * 8;
             if (c < C) {
                 float xv[8];
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                     xh[k][t] = (xv[t] - mu) * rs;
                     dg[k][t] += gv[k][t] * xh[k][t];
                     db[k][t] += gv[k][t];
-                    gv[k][t] *= gamma[c + t];
+                    gv[k][t] *= gam[k][t];
                     s1 += gv[k][t];
                     s2 += gv[k][t] * xh[k][t];
                 }
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-        for (int k = 0; k < LN_MAXCH; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int c = (lane + k * 64) * 8;
             if (c < C) {
                 float o[8];
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
         }
     }
 #pragma unroll
-    for (int k = 0; k < LN_MAXCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         const int c = (lane + k * 64) * 8;
         if (c < C) {
 #pragma unroll
@@ -558,23 +568,28 @@ int launch_layernorm_fwd(hipStream_t st, const uint16_t* x, const float* gamma, 
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-static int rows_blocks(int rows, int per_iter, int* rpb) {
+// LayerNorm backward: 3 workgroups per CU in ONE round (25216 rows: 701 workgroups of 36 rows 56 us; 788 of 32 rows = 3.08 per CU 78 us,
+// 512 of 52 rows 67 us); DALI_LN_BLOCKS overrides (A/B aid)
+static int ln_block_cap() { static int v = -1; if (v < 0) { const char* e = getenv("DALI_LN_BLOCKS"); v = e ? atoi(e) : 768; } return v; }
+static int rows_blocks(int rows, int per_iter, int* rpb, int cap = 2048) {
     int blocks = (rows + per_iter * 8 - 1) / (per_iter * 8);
-    if (blocks > 512) blocks = 512;
+    if (blocks > cap) blocks = cap;                    // column sums: 8 workgroups per CU (512 left too few rows in flight: 26 -> 17 us)
     if (blocks < 1) blocks = 1;
     int r = (rows + blocks - 1) / blocks;
     r = (r + per_iter - 1) / per_iter * per_iter;
     *rpb = r;
     return (rows + r - 1) / r;
 }
-size_t layernorm_bwd_partial_floats(int rows, int C) { int rpb; return (size_t)rows_blocks(rows, 4, &rpb) * C * 2; }
+size_t layernorm_bwd_partial_floats(int rows, int C) { int rpb; return (size_t)rows_blocks(rows, 4, &rpb, 2048) * C * 2; }   // sized for any cap
 int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, const float* gamma, const float* mean, const float* rstd,
                          const uint16_t* add, int rows, int C, uint16_t* dx, float* dgamma, float* dbeta, float* partial, double* scratch,
                          const float* g32) {
     int rpb;
-    const int blocks = rows_blocks(rows, 4, &rpb);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), (size_t)4 * C * 2 * sizeof(float), st, g, x, gamma, mean, rstd, add, rows, C,
-                       rpb, dx, partial, g32);
+    const int blocks = rows_blocks(rows, 4, &rpb, ln_block_cap());
+    const size_t lds = (size_t)4 * C * 2 * sizeof(float);
+    if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
+    else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<LN_MAXCH>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     DALI_LAUNCH_CHECK();
     int S, rc;
     if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
