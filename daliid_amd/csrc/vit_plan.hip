@@ -176,12 +176,12 @@ extern "C" int dali_vit_refresh_weights(dali_vit* n, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_cast_bf16(st, n->P, (size_t)n->param_elems, n->wbf16);
     if (rc) return rc;
+    std::vector<TransposeJob> jobs;                      // every linear's dgrad image [K][N], batched launches (48 single launches cost 0.3 ms)
     for (auto& b : n->blocks) {
         Lin* ls[4] = {&b.qkv, &b.proj, &b.fc1, &b.fc2};
-        for (Lin* l : ls)
-            if ((rc = launch_weight_transpose(st, l->w, l->N, 1, l->K, l->wt))) return rc;     // [N][K] -> [K][N]
+        for (Lin* l : ls) jobs.push_back(TransposeJob{l->w, l->wt, l->N, 1, l->K, 0});          // [N][K] -> [K][N]
     }
-    return DALI_OK;
+    return launch_weight_transpose_batched(st, jobs.data(), (int)jobs.size());
 }
 
 extern "C" int dali_vit_forward(dali_vit* n, void* stream, const float* images, int training, float* feat, float* global_feat) {
