@@ -19,5 +19,11 @@ out = ["# Round 1 -- gallery distance (configs[4]) kernel profile\n",
 for r in rows[:12]:
     out.append("| `%s` | %s | %.3f | %.1f | %.1f | %.1f | %.1f |" % (r["Name"][:100].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                                  float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["Percentage"])))
+try:
+    clk = open(src + "/clock.txt").read().strip()
+    out.append("\nEffective shader clock during the distance kernel (`rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace` in its own run, "
+               "`scripts/effective_clock.py`: GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time; the 2.5 PFLOP/s dense bf16 peak is quoted at 2.4 GHz):\n\n```\n%s\n```\n" % clk)
+except OSError:
+    pass
 open("profiles/r01_distance_kernel_stats.md", "w").write("\n".join(out) + "\n")
 print("wrote profiles/r01_distance_kernel_stats.md")

@@ -9,3 +9,6 @@ timeout -k 10 300 python bench.py --workload distance --steps 5 --warmup 2 --pre
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --workload distance --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_prof.json 2> $O/stats.err || exit 3
 timeout -k 10 200 python scripts/time_rank.py > $O/rank.txt 2>> $O/bench.err || exit 4
 cp $(ls $O/stats/*/*kernel_stats.csv | head -n 1) $O/kernel_stats.csv
+# effective shader clock during the distance kernel (DVFS: the chip does not hold 2.4 GHz under dense MFMA load)
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/clock -- python bench.py --workload distance --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/clock.err || exit 5
+python scripts/effective_clock.py $O/clock pairdist_dma > $O/clock.txt
