@@ -886,6 +886,42 @@ __device__ __forceinline__ bf16x8_t tr_frag(const uint16_t* tile, int chunk32, i
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// The same reads through inline asm.  With LDS-DMA writes in flight the compiler puts `s_waitcnt vmcnt(0)` in front of the first
+// __builtin_amdgcn_ds_read_tr16_b64 of a k-step (it cannot prove that the read does not alias the DMA destination; plain
+// ds_read_b128 loads do not get that wait), which makes every k-step wait for the tile it has just requested: the ring never
+// overlaps anything.  The asm form is invisible to that analysis; in exchange the caller must wait for the data itself with
+// tr_settle (the halves are passed through it as in/out operands, so nothing that uses them can be scheduled above the wait).
+struct TrPair { s16x4_t lo, hi; };
+__device__ __forceinline__ s16x4_t ds_read_tr_raw(const uint16_t* p) {
+    typedef __attribute__((address_space(3))) const uint16_t* lds_cptr_t;
+    const uint32_t addr = (uint32_t)(uintptr_t)(lds_cptr_t)p;
+    s16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ TrPair tr_frag_raw(const uint16_t* tile, int chunk32, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row0 = 8 * g + q, row1 = row0 + 4;
+    const int off0 = row0 * 128 + ((chunk32 ^ wg_swz(row0)) << 4) + 4 * p;
+    const int off1 = row1 * 128 + ((chunk32 ^ wg_swz(row1)) << 4) + 4 * p;
+    return TrPair{ds_read_tr_raw(tile + off0), ds_read_tr_raw(tile + off1)};
+}
+__device__ __forceinline__ bf16x8_t tr_join(const TrPair& t) {
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = {t.lo[0], t.lo[1], t.lo[2], t.lo[3], t.hi[0], t.hi[1], t.hi[2], t.hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// wait until at most N LDS reads of this wave are outstanding; the four pairs are "used and redefined" by the wait
+template <int N>
+__device__ __forceinline__ void tr_settle(TrPair& a, TrPair& b, TrPair& c, TrPair& d) {
+    static_assert(N == 0 || N == 8 || N == 10 || N == 16 || N == 18, "lgkmcnt immediates used by the callers");
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi));
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi));
+    else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi));
+    else if constexpr (N == 16) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi));
+    else asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi));
+}
+
 template <bool IN_BN>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WGradArgs a, int tiles_m, int tiles_n) {
     constexpr int TILE = 32 * 128;                       // elements per operand per stage
@@ -1069,12 +1105,20 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
             if (kt + 2 < ksteps) issue(kt + 2, st_nxt2);
             const uint16_t* sa = smem + st_cur * 2 * TILE;
             const uint16_t* sb = sa + TILE;
+            // transposing reads through inline asm (see ds_read_tr_raw): 16 reads in order, A (8) then B (8)
+            TrPair ra[4], rb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = tr_frag_raw(sa, wm * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb[j] = tr_frag_raw(sb, wn * 4 + j, lane);
+            tr_settle<8>(ra[0], ra[1], ra[2], ra[3]);
+            tr_settle<0>(rb[0], rb[1], rb[2], rb[3]);
             bf16x8_t fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, wm * 4 + i, lane);
+            for (int i = 0; i < 4; ++i) fa[i] = tr_join(ra[i]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bf16x8_t fb = tr_frag(sb, wn * 4 + j, lane);
+                const bf16x8_t fb = tr_join(rb[j]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
             }
@@ -1191,8 +1235,6 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
     // transposing read of the halo patch: lane group gq = lane>>4 covers pixels 8*gq .. 8*gq+7 of the k-step
     const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int hrow_base = ((8 * gq) >> lw) * HC + ((8 * gq) & (W - 1)) + q;    // halo row of (tap 0,0), first of the two reads
-    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
-    typedef short s16x8_t __attribute__((ext_vector_type(8)));
     // the 9 taps' read offsets inside the patch do not depend on the k-step: computed once
     int boff0[9], boff1[9];
 #pragma unroll
@@ -1203,12 +1245,7 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
             boff0[r * 3 + s2] = row0 * 64 + ((wn ^ halo_swz(row0)) << 4) + 4 * pp;
             boff1[r * 3 + s2] = row1 * 64 + ((wn ^ halo_swz(row1)) << 4) + 4 * pp;
         }
-    auto load_b = [&](const uint16_t* sb, int t) -> bf16x8_t {
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(sb + boff0[t]));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(sb + boff1[t]));
-        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8_t, v);
-    };
+    auto load_b = [&](const uint16_t* sb, int t) -> TrPair { return TrPair{ds_read_tr_raw(sb + boff0[t]), ds_read_tr_raw(sb + boff1[t])}; };
 
     // NSTAGE-deep ring, NSTAGE-1 k-steps in flight: with one 8-wave block per CU the bytes in flight are what hides the
     // ~2 us load latency (3 stages: 1.25 us per k-step, load-latency-bound; the MFMA work is 0.5 us)
@@ -1233,19 +1270,33 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
             const uint16_t* sa = smem + st_cur * W3_STAGE;
             const uint16_t* sb = sa + W3_A_ELEMS;
             if (m_active) {
+            // 26 transposing reads (inline asm, see ds_read_tr_raw) in program order: A (8), taps 0..3 (8), taps 4..8 (10); the
+            // MFMAs of a group start once the reads before the next group's have returned (LDS reads return in order)
+            TrPair ra[4], rb[9];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = tr_frag_raw(sa, wm * 4 + i, lane);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) rb[t] = load_b(sb, t);
+            tr_settle<18>(ra[0], ra[1], ra[2], ra[3]);              // <= 15 outstanding is all the counter can express: A has landed
+            tr_settle<10>(rb[0], rb[1], rb[2], rb[3]);
             bf16x8_t fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, wm * 4 + i, lane);
-            // all nine taps' fragments are requested up front (36 VGPRs): one exposed LDS latency per k-step instead of nine
-            // (the compiler otherwise sinks every read to just before its MFMAs, with a full lgkmcnt wait each time)
-            bf16x8_t fb[9];
+            for (int i = 0; i < 4; ++i) fa[i] = tr_join(ra[i]);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) fb[t] = load_b(sb, t);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t fb = tr_join(rb[t]);
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[t][i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                       // keep the first 16 MFMAs above the second wait
+            tr_settle<0>(rb[4], rb[5], rb[6], rb[7]);
+            tr_settle<0>(rb[8], rb[8], rb[8], rb[8]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[t], acc[t][i], 0, 0, 0);
+            for (int t = 4; t < 9; ++t) {
+                const bf16x8_t fb = tr_join(rb[t]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[t][i], 0, 0, 0);
+            }
             }
             // k-step kt+1 must have landed: everything but the youngest min(AHEAD - 1, remaining - 1) k-steps
             const int left = ksteps - 1 - kt;
@@ -1370,12 +1421,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs 
             if (kt + AHEAD < ksteps) issue(kt + AHEAD, st_fill);
             const uint16_t* sa = smem + st_cur * NIMG * IMG + (wm >> 1) * IMG;
             const uint16_t* sb = smem + st_cur * NIMG * IMG + (NIMG_A + (wn >> 1)) * IMG;
+            TrPair ra[4], rb[4];                                     // inline-asm transposing reads, see ds_read_tr_raw
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = tr_frag_raw(sa, (wm & 1) * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb[j] = tr_frag_raw(sb, (wn & 1) * 4 + j, lane);
+            tr_settle<8>(ra[0], ra[1], ra[2], ra[3]);
+            tr_settle<0>(rb[0], rb[1], rb[2], rb[3]);
             bf16x8_t fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, (wm & 1) * 4 + i, lane);
+            for (int i = 0; i < 4; ++i) fa[i] = tr_join(ra[i]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bf16x8_t fb = tr_frag(sb, (wn & 1) * 4 + j, lane);
+                const bf16x8_t fb = tr_join(rb[j]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
             }
