@@ -1879,10 +1879,20 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
 // on the 1x1 layers with a long pixel (K) dimension; on 3x3 layers (each 128-column group of N is one tap's gather)
 // and on the ViT linears (25 k rows: the split-K slabs double) they lose.
 // DALI_WGRAD_SPEC=0 (A/B aid): the unspecialised 128 x 256 weight-gradient kernel, two workgroups per CU
-static int wgrad_spec() {
-    static int v = -1;
-    if (v == -1) { const char* e = getenv("DALI_WGRAD_SPEC"); v = e ? atoi(e) : 1; }
+static int wgrad_spec_env() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("DALI_WGRAD_SPEC"); v = e ? atoi(e) : -1; }
     return v;
+}
+// the 128 x 256 weight-gradient kernel: wave-specialised (one workgroup per CU) when the problem has few output tiles, the plain
+// 8-wave kernel (two workgroups per CU = 16 MFMA waves) when the tiles alone nearly fill the chip.  DALI_WGRAD_SPEC=0/1 forces one
+// form, DALI_WGRAD_SPEC_TILES moves the threshold (A/B aids).
+static bool wgrad_spec(int Cm, int Ntot) {
+    const int ov = wgrad_spec_env();
+    if (ov >= 0) return ov != 0;
+    static int thr = -1;
+    if (thr < 0) { const char* e = getenv("DALI_WGRAD_SPEC_TILES"); thr = e ? atoi(e) : 40; }
+    return ((Cm + 127) / 128) * ((Ntot + 255) / 256) <= thr;
 }
 int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P, int halo_w) {
     static int ov = -2;
@@ -1900,7 +1910,7 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
     const int cfg = wgrad_pick_cfg(Cm, Ntot, taps, P, halo_w);
     const int TMc = cfg == 1 ? 256 : 128, TNc = cfg == 0 ? 128 : (cfg == 3 ? 9 * 64 : 256);
     if (cfg == 1 || cfg == 3) target_blocks = 256;  // one 16-wave / 8-wave block per CU
-    if (cfg == 2) target_blocks = wgrad_spec() ? 256 : 512;     // one 16-wave (specialised) / two 8-wave blocks per CU
+    if (cfg == 2) target_blocks = wgrad_spec(Cm, Ntot) ? 256 : 512;     // one 16-wave (specialised) / two 8-wave blocks per CU
     const int tiles = ((Cm + TMc - 1) / TMc) * ((Ntot + TNc - 1) / TNc);
     int sp = (target_blocks + tiles - 1) / tiles;
     const int max_sp = (P + 255) / 256;              // at least 8 k-steps per block
@@ -1947,7 +1957,7 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
             attr_set = true;
         }
-        if (wgrad_spec()) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
+        if (wgrad_spec(a.Cm, a.Ntot)) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
         else hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm2, tn2);
     } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
