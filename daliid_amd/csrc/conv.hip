@@ -1941,7 +1941,8 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     if (!a.in_scale && dma_ok && wcfg == 3) {
         static bool attr_set = false;
         const int tm3 = (a.Cm + 127) / 128, tn3 = a.g.Ck / 64;
-        const int lds = 3 * W3_STAGE * 2;            // 3 stages x 24 KiB (deeper rings measured the same: the loop is issue-bound)
+        const int lds = 3 * W3_STAGE * 2;            // 3 stages x 24 KiB (4 and 5 measured the same, before and after the inline-asm reads: the
+                                                     // k-step is bound by its 26 transposing reads + 36 MFMAs per wave, two waves per SIMD)
         if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
         hipLaunchKernelGGL(igemm_wgrad3x3_kernel<3>, dim3(((tm3 * tn3 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm3, tn3);
     } else if (!a.in_scale && dma_ok && wcfg == 1) {
