@@ -1,5 +1,6 @@
-"""Development aid: forward time of a few large conv layers (the wave-grid kernels) -- run once per library variant
-(normal / -DDALI_ABLATE=1: no MFMA / =2: no fragment reads either) to see which resource bounds the main loop."""
+"""Development aid: forward time of a few large conv layers (the wave-grid kernels), run once per library variant to see which
+resource bounds the main loop.  The variants were temporary builds of conv.hip with the MFMAs / the fragment reads / the DMA issue
+of the k-loop compiled out under a macro (not kept in the source); results in DESIGN.md section 4."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,5 @@
-"""Development aid: 3x3 weight-gradient time of a few layers -- run per library variant (normal / -DW3_ABLATE=1 no MFMA / =2 no DMA)."""
+"""Development aid: 3x3 weight-gradient time of a few layers, run per library variant (normal / MFMAs compiled out / DMA issue
+compiled out: temporary builds, the macro is not kept in the source)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
