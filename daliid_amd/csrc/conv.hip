@@ -922,6 +922,8 @@ __device__ __forceinline__ void tr_settle(TrPair& a, TrPair& b, TrPair& c, TrPai
     else asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi));
 }
 
+__device__ __forceinline__ void tr_settle_all(TrPair& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi)); }
+
 template <bool IN_BN>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WGradArgs a, int tiles_m, int tiles_n) {
     constexpr int TILE = 32 * 128;                       // elements per operand per stage
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
             }
             __builtin_amdgcn_sched_barrier(0);                       // keep the first 16 MFMAs above the second wait
             tr_settle<0>(rb[4], rb[5], rb[6], rb[7]);
-            tr_settle<0>(rb[8], rb[8], rb[8], rb[8]);
+            tr_settle_all(rb[8]);
 #pragma unroll
             for (int t = 4; t < 9; ++t) {
                 const bf16x8_t fb = tr_join(rb[t]);
