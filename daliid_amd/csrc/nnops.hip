@@ -386,25 +386,36 @@ __global__ __launch_bounds__(256) void maxpool_bn_fwd_kernel(const uint16_t* __r
 // dz[n,h,w,c] = sum over the (<=4) windows containing (h,w) of dp[window] * [arg[window] == tap of (h,w)]
 __device__ __forceinline__ void maxpool_gather_dz(const uint16_t* __restrict__ dp, const uint8_t* __restrict__ arg, int n, int h, int w,
                                                   int cc, int C, int Ho, int Wo, float (&dz)[8]) {
+    // 3x3 / stride 2 / pad 1: row h lies in window h>>1 (at offset 1 for even h, 2 for odd h) and, for odd h, in window (h>>1)+1 at
+    // offset 0; the same for columns.  The (up to) four windows are read unconditionally from clamped addresses and gated by a
+    // predicate, so the four load pairs are in flight together (the data-dependent 1..2 x 1..2 loops serialised them).
+    const int ho0 = h >> 1, wo0 = w >> 1;
+    const int rh[2] = {1 + (h & 1), 0}, rw[2] = {1 + (w & 1), 0};           // offsets inside window 0 / window 1
+    const bool vh[2] = {ho0 < Ho, (h & 1) && ho0 + 1 < Ho}, vw[2] = {wo0 < Wo, (w & 1) && wo0 + 1 < Wo};
+    uint4 gq[4];
+    uint2 aq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int a = k >> 1, b = k & 1;
+        const int ho = min(ho0 + a, Ho - 1), wo = min(wo0 + b, Wo - 1);
+        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + cc;
+        aq[k] = *reinterpret_cast<const uint2*>(arg + o);
+        gq[k] = *reinterpret_cast<const uint4*>(dp + o);
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) dz[t] = 0.f;
-    const int ho_lo = (h >= 1) ? (h - 1 + 1) / 2 : 0;      // ceil((h-1)/2)
-    const int ho_hi = min(Ho - 1, (h + 1) / 2);
-    const int wo_lo = (w >= 1) ? (w - 1 + 1) / 2 : 0;
-    const int wo_hi = min(Wo - 1, (w + 1) / 2);
-    for (int ho = ho_lo; ho <= ho_hi; ++ho)
-        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-            const int tap = (h - (ho * 2 - 1)) * 3 + (w - (wo * 2 - 1));
-            const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + cc;
-            const uint2 av = *reinterpret_cast<const uint2*>(arg + o);
-            float g[8];
-            unpack8(*reinterpret_cast<const uint4*>(dp + o), g);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int a = (t < 4 ? (av.x >> (8 * t)) : (av.y >> (8 * (t - 4)))) & 0xff;
-                if (a == tap) dz[t] += g[t];
-            }
+    for (int k = 0; k < 4; ++k) {                                            // same order as the loops it replaces: (ho, wo) ascending
+        const int a = k >> 1, b = k & 1;
+        const int tap = (vh[a] && vw[b]) ? rh[a] * 3 + rw[b] : -1;
+        float g[8];
+        unpack8(gq[k], g);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int av = (t < 4 ? (aq[k].x >> (8 * t)) : (aq[k].y >> (8 * (t - 4)))) & 0xff;
+            if (av == tap) dz[t] += g[t];
         }
+    }
 }
 
 // pass 1: partial sums of dz and dz*xhat over the stem output;  pass 2: d_raw = scale*(dz - S1/N - xhat*S2/N)
@@ -446,18 +457,19 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const uint16_
                                                                     const float* __restrict__ invstd, const float* __restrict__ coef,
                                                                     int N, int H, int W, int C, int Ho, int Wo, uint16_t* __restrict__ draw) {
     const int cpr = C >> 3;
-    const size_t total = (size_t)N * H * W * cpr;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cc = (int)(i % cpr) * 8;
-        const size_t p = i / cpr;
-        const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+    const unsigned total = (unsigned)N * H * W * cpr;              // < 2^32 (checked by the launcher): 32-bit index arithmetic
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int cc = (int)(i % (unsigned)cpr) * 8;
+        const unsigned p = i / (unsigned)cpr;
+        const unsigned pw = p / (unsigned)W;
+        const int w = (int)(p - pw * W), n = (int)(pw / (unsigned)H), h = (int)(pw - (unsigned)n * H);
         float dz[8], rv[8], A[8], K[8], Q[8], o[8];
         maxpool_gather_dz(dp, arg, n, h, w, cc, C, Ho, Wo, dz);
-        unpack8(*reinterpret_cast<const uint4*>(raw + p * C + cc), rv);
+        unpack8(*reinterpret_cast<const uint4*>(raw + (size_t)p * C + cc), rv);
         load8f(coef + cc, A); load8f(coef + C + cc, K); load8f(coef + 2 * C + cc, Q);
 #pragma unroll
         for (int t = 0; t < 8; ++t) o[t] = A[t] * dz[t] + K[t] - Q[t] * rv[t];
-        *reinterpret_cast<uint4*>(draw + p * C + cc) = pack8(o);
+        *reinterpret_cast<uint4*>(draw + (size_t)p * C + cc) = pack8(o);
     }
 }
 
@@ -754,6 +766,7 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
                           uint16_t* draw, double* scratch) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int P = N * H * W;
+    if ((long long)P * (C / 8) >= (1ll << 32)) { set_error("maxpool_bn_bwd: more than 2^32 16-byte chunks"); return DALI_ERR_LIMIT; }
     int rpb;
     const int blocks = bn_bwd_blocks(P, C, &rpb);
     const int rif = 256 / (C / 8);
