@@ -104,11 +104,23 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint16_t* __restrict_
                                                       const uint16_t* __restrict__ raw2, const float* __restrict__ scale2,
                                                       const float* __restrict__ shift2, int relu, size_t chunks, int C,
                                                       uint16_t* __restrict__ y, uint8_t* __restrict__ mask_out) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
-        const int c = (int)((i * 8) % (size_t)C);
-        float v[8], sc[8], sh[8];
+    // A thread's channel chunk is the same in every grid-stride iteration when the stride is a multiple of C (always, for the
+    // power-of-two widths of the net): the coefficients are then loaded once, not per 16 bytes of data, and the 64-bit modulo
+    // leaves the loop.
+    const size_t first = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool fixed_c = ((size_t)gridDim.x * 2048) % (size_t)C == 0;
+    int c = (int)((first * 8) % (size_t)C);
+    float sc[8], sh[8], sc2[8], sh2[8];
+    load8f(scale + c, sc); load8f(shift + c, sh);
+    if (raw2) { load8f(scale2 + c, sc2); load8f(shift2 + c, sh2); }
+    for (size_t i = first; i < chunks; i += (size_t)gridDim.x * 256) {
+        if (!fixed_c) {
+            c = (int)((i * 8) % (size_t)C);
+            load8f(scale + c, sc); load8f(shift + c, sh);
+            if (raw2) { load8f(scale2 + c, sc2); load8f(shift2 + c, sh2); }
+        }
+        float v[8];
         unpack8(*reinterpret_cast<const uint4*>(raw + i * 8), v);
-        load8f(scale + c, sc); load8f(shift + c, sh);
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] = v[t] * sc[t] + sh[t];
         if (idn) {
@@ -119,9 +131,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const uint16_t* __restrict_
         } else if (raw2) {
             float r[8];
             unpack8(*reinterpret_cast<const uint4*>(raw2 + i * 8), r);
-            load8f(scale2 + c, sc); load8f(shift2 + c, sh);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] += r[t] * sc[t] + sh[t];
+            for (int t = 0; t < 8; ++t) v[t] += r[t] * sc2[t] + sh2[t];
         }
         if (relu) {
 #pragma unroll
@@ -267,8 +278,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
                                                             const float* __restrict__ coef_a, const float* __restrict__ coef_b, int relu,
                                                             size_t chunks, int C, uint16_t* __restrict__ draw_a,
                                                             uint16_t* __restrict__ draw_b, uint16_t* __restrict__ dz_out) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
-        const int c = (int)((i * 8) % (size_t)C);
+    // coefficients once per thread when the grid stride is a multiple of C (see bn_act_kernel)
+    const size_t first = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool fixed_c = ((size_t)gridDim.x * 2048) % (size_t)C == 0;
+    const bool need_relu_coef = !ybits && !ymask && relu;
+    int c = (int)((first * 8) % (size_t)C);
+    float A[8], K[8], Q[8], A2[8], K2[8], Q2[8], sa[8], ha[8];
+    auto load_coef = [&]() {
+        load8f(coef_a + c, A); load8f(coef_a + C + c, K); load8f(coef_a + 2 * C + c, Q);
+        if (DUAL) { load8f(coef_b + c, A2); load8f(coef_b + C + c, K2); load8f(coef_b + 2 * C + c, Q2); }
+        if (need_relu_coef) { load8f(a.scale + c, sa); load8f(a.shift + c, ha); }
+    };
+    load_coef();
+    for (size_t i = first; i < chunks; i += (size_t)gridDim.x * 256) {
+        if (!fixed_c) { c = (int)((i * 8) % (size_t)C); load_coef(); }
         float gv[8], rv[8];
         unpack8(*reinterpret_cast<const uint4*>(g + i * 8), gv);
         unpack8(*reinterpret_cast<const uint4*>(a.raw + i * 8), rv);
@@ -282,21 +305,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
 #pragma unroll
             for (int t = 0; t < 8; ++t) gv[t] = yv[t] > 0.f ? gv[t] : 0.f;
         } else if (relu) {
-            float sa[8], ha[8];
-            load8f(a.scale + c, sa); load8f(a.shift + c, ha);
 #pragma unroll
             for (int t = 0; t < 8; ++t) gv[t] = (rv[t] * sa[t] + ha[t]) > 0.f ? gv[t] : 0.f;
         }
-        float A[8], K[8], Q[8], o[8];
-        load8f(coef_a + c, A); load8f(coef_a + C + c, K); load8f(coef_a + 2 * C + c, Q);
+        float o[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) o[t] = A[t] * gv[t] + K[t] - Q[t] * rv[t];
         if (DUAL) {
             float r2[8], o2[8];
             unpack8(*reinterpret_cast<const uint4*>(b.raw + i * 8), r2);
-            load8f(coef_b + c, A); load8f(coef_b + C + c, K); load8f(coef_b + 2 * C + c, Q);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) o2[t] = A[t] * gv[t] + K[t] - Q[t] * r2[t];
+            for (int t = 0; t < 8; ++t) o2[t] = A2[t] * gv[t] + K2[t] - Q2[t] * r2[t];
             *reinterpret_cast<uint4*>(draw_b + i * 8) = pack8(o2);
         }
         if (dz_out) *reinterpret_cast<uint4*>(dz_out + i * 8) = pack8(gv);     // may alias g (same index, read first)
