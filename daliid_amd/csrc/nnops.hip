@@ -496,43 +496,60 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const uint16_
 // Head: f[n,c] = mean_hw x + max_hw x (Encoders.py:341-345), fp32 out, argmax kept for the backward.
 // mode: DALI_FEATURE_BOTH / _GAP (mean only) / _GMP (max only) = the `feature` switch of evaluateCleanATModels.py:335-340.
 // ------------------------------------------------------------------------------------------------
+// 8 lanes share one (image, 8-channel chunk): lane s takes pixels s, s+8, ... and the 8 partial (sum, max, argmax) are combined by
+// shuffles (ties: the lowest pixel index wins, as in a sequential scan with `>`).  One thread per chunk walking all HW pixels was
+// latency-bound (84 us for 134 MB).
 __global__ __launch_bounds__(256) void head_pool_fwd_kernel(const uint16_t* __restrict__ x, int N, int HW, int C, int mode,
                                                              float* __restrict__ f, int16_t* __restrict__ arg) {
     const int cpr = C >> 3;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * cpr) return;
-    const int cc = (i % cpr) * 8, n = i / cpr;
+    const int item = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const bool live = item < N * cpr;
+    const int cc = live ? (item % cpr) * 8 : 0, n = live ? item / cpr : 0;
     float sum[8], best[8];
     int bi[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { sum[t] = 0.f; best[t] = -__builtin_inff(); bi[t] = 0; }
-    for (int p = 0; p < HW; ++p) {
-        float v[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p) * C + cc), v);
+    for (int t = 0; t < 8; ++t) { sum[t] = 0.f; best[t] = -__builtin_inff(); bi[t] = 0x7fffffff; }
+    if (live)
+        for (int p = sub; p < HW; p += 8) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p) * C + cc), v);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { sum[t] += v[t]; if (v[t] > best[t]) { best[t] = v[t]; bi[t] = p; } }
-    }
+            for (int t = 0; t < 8; ++t) { sum[t] += v[t]; if (v[t] > best[t]) { best[t] = v[t]; bi[t] = p; } }
+        }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        f[(size_t)n * C + cc + t] = (mode == DALI_FEATURE_GMP ? 0.f : sum[t] / (float)HW) + (mode == DALI_FEATURE_GAP ? 0.f : best[t]);
-        arg[(size_t)n * C + cc + t] = (int16_t)bi[t];
+    for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            sum[t] += __shfl_xor(sum[t], o, 64);
+            const float ob = __shfl_xor(best[t], o, 64);
+            const int oi = __shfl_xor(bi[t], o, 64);
+            if (ob > best[t] || (ob == best[t] && oi < bi[t])) { best[t] = ob; bi[t] = oi; }
+        }
+    if (live && sub == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f[(size_t)n * C + cc + t] = (mode == DALI_FEATURE_GMP ? 0.f : sum[t] / (float)HW) + (mode == DALI_FEATURE_GAP ? 0.f : best[t]);
+            arg[(size_t)n * C + cc + t] = (int16_t)bi[t];
+        }
     }
 }
 __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restrict__ df, const int16_t* __restrict__ arg, int N, int HW,
                                                              int C, int mode, uint16_t* __restrict__ dx) {
     const int cpr = C >> 3;
-    const size_t total = (size_t)N * HW * cpr;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cc = (int)(i % cpr) * 8;
-        const size_t pix = i / cpr;
-        const int p = (int)(pix % HW), n = (int)(pix / HW);
+    const unsigned total = (unsigned)N * HW * cpr;              // < 2^32 (checked by the launcher): 32-bit index arithmetic
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned pix = i / (unsigned)cpr;
+        const int cc = (int)(i - pix * cpr) * 8;
+        const int n = (int)(pix / (unsigned)HW), p = (int)(pix - (unsigned)n * HW);
         float g[8], o[8];
         load8f(df + (size_t)n * C + cc, g);
+        const uint4 av = *reinterpret_cast<const uint4*>(arg + (size_t)n * C + cc);
+        const int a[8] = {(int)(int16_t)(av.x & 0xffff), (int)(int16_t)(av.x >> 16), (int)(int16_t)(av.y & 0xffff), (int)(int16_t)(av.y >> 16),
+                          (int)(int16_t)(av.z & 0xffff), (int)(int16_t)(av.z >> 16), (int)(int16_t)(av.w & 0xffff), (int)(int16_t)(av.w >> 16)};
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            o[t] = (mode == DALI_FEATURE_GMP ? 0.f : g[t] / (float)HW) +
-                   ((mode != DALI_FEATURE_GAP && (int)arg[(size_t)n * C + cc + t] == p) ? g[t] : 0.f);
-        *reinterpret_cast<uint4*>(dx + pix * C + cc) = pack8(o);
+            o[t] = (mode == DALI_FEATURE_GMP ? 0.f : g[t] / (float)HW) + ((mode != DALI_FEATURE_GAP && a[t] == p) ? g[t] : 0.f);
+        *reinterpret_cast<uint4*>(dx + (size_t)pix * C + cc) = pack8(o);
     }
 }
 
@@ -833,11 +850,12 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     return DALI_OK;
 }
 int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, int mode, float* f, int16_t* arg) {
-    hipLaunchKernelGGL(head_pool_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, st, x, N, HW, C, mode, f, arg);
+    hipLaunchKernelGGL(head_pool_fwd_kernel, dim3((N * (C / 8) * 8 + 255) / 256), dim3(256), 0, st, x, N, HW, C, mode, f, arg);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, int mode, uint16_t* dx) {
+    if ((long long)N * HW * (C / 8) >= (1ll << 32)) { set_error("head_pool_bwd: more than 2^32 16-byte chunks"); return DALI_ERR_LIMIT; }
     hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, st, df, arg, N, HW, C, mode, dx);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
