@@ -492,6 +492,62 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const uint16_
     }
 }
 
+// Apply pass on 2 x 2 pixel quads (H, W even): the four pixels of a quad draw on the same four pooling windows, so a thread loads each
+// (dp, arg) window once instead of once per pixel (the gather above re-reads every window four times: 400 MB of L2 traffic for a
+// 67 MB tensor).  Per pixel the windows are added in the same (ho, wo) order as maxpool_gather_dz: bit-identical results.
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_quad_kernel(const uint16_t* __restrict__ dp, const uint8_t* __restrict__ arg,
+                                                                         const uint16_t* __restrict__ raw, const float* __restrict__ coef,
+                                                                         int N, int H, int W, int C, int Ho, int Wo, uint16_t* __restrict__ draw) {
+    const int cpr = C >> 3;
+    const unsigned total = (unsigned)N * Ho * Wo * cpr;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned q = i / (unsigned)cpr;
+        const int cc = (int)(i - q * cpr) * 8;
+        const unsigned qrow = q / (unsigned)Wo;
+        const int j = (int)(q - qrow * Wo), n = (int)(qrow / (unsigned)Ho), k = (int)(qrow - (unsigned)n * Ho);
+        float A[8], K[8], Q[8];
+        load8f(coef + cc, A); load8f(coef + C + cc, K); load8f(coef + 2 * C + cc, Q);
+        // windows (k, j), (k, j+1), (k+1, j), (k+1, j+1): clamped addresses, validity as predicates
+        float g[4][8];
+        int av[4][8];
+        const bool vk = k + 1 < Ho, vj = j + 1 < Wo;
+#pragma unroll
+        for (int wdx = 0; wdx < 4; ++wdx) {
+            const int ho = min(k + (wdx >> 1), Ho - 1), wo = min(j + (wdx & 1), Wo - 1);
+            const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + cc;
+            const uint2 a2 = *reinterpret_cast<const uint2*>(arg + o);
+            unpack8(*reinterpret_cast<const uint4*>(dp + o), g[wdx]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) av[wdx][t] = (int)(((t < 4 ? (a2.x >> (8 * t)) : (a2.y >> (8 * (t - 4)))) & 0xff));
+        }
+        // (window, tap) lists per pixel (a, b) of the quad, in (ho, wo) order; tap = row offset * 3 + column offset inside the window
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                float dz[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) dz[t] = 0.f;
+#pragma unroll
+                for (int wdx = 0; wdx < 4; ++wdx) {
+                    const int da = wdx >> 1, db = wdx & 1;
+                    if ((da && !pa) || (db && !pb)) continue;                 // an even row / column lies in one window only
+                    const bool ok = (!da || vk) && (!db || vj);
+                    const int tap = ok ? (da ? 0 : 1 + pa) * 3 + (db ? 0 : 1 + pb) : -1;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (av[wdx][t] == tap) dz[t] += g[wdx][t];
+                }
+                const size_t p = ((size_t)n * H + 2 * k + pa) * W + 2 * j + pb;
+                float rv[8], o8[8];
+                unpack8(*reinterpret_cast<const uint4*>(raw + p * C + cc), rv);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o8[t] = A[t] * dz[t] + K[t] - Q[t] * rv[t];
+                *reinterpret_cast<uint4*>(draw + p * C + cc) = pack8(o8);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Head: f[n,c] = mean_hw x + max_hw x (Encoders.py:341-345), fp32 out, argmax kept for the backward.
 // mode: DALI_FEATURE_BOTH / _GAP (mean only) / _GMP (max only) = the `feature` switch of evaluateCleanATModels.py:335-340.
@@ -844,8 +900,12 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, 2, 1, (double)P, scale, mean, invstd, coef,
                        dgamma, dbeta);
     DALI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 8))), dim3(256), 0, st, dp, arg, raw, mean, invstd, coef, N, H,
-                       W, C, Ho, Wo, draw);
+    if ((H & 1) == 0 && (W & 1) == 0)
+        hipLaunchKernelGGL(maxpool_bn_bwd_apply_quad_kernel, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(256), 0, st, dp, arg, raw, coef, N, H, W, C,
+                           Ho, Wo, draw);
+    else
+        hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(grid_for((size_t)P * (C / 8))), dim3(256), 0, st, dp, arg, raw, mean, invstd, coef, N, H,
+                           W, C, Ho, Wo, draw);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
