@@ -492,6 +492,70 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const uint16_
     }
 }
 
+// Reduce pass on 2 x 2 pixel quads (H, W even), same window sharing as the apply pass below; a block owns a range of quads.
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_quad_kernel(const uint16_t* __restrict__ dp, const uint8_t* __restrict__ arg,
+                                                                          const uint16_t* __restrict__ raw, const float* __restrict__ mean,
+                                                                          const float* __restrict__ invstd, int N, int H, int W, int C,
+                                                                          int Ho, int Wo, int quads_per_block, float* __restrict__ partial) {
+    extern __shared__ float red[];                  // [rif][C][2]
+    const int cpr = C >> 3, rif = 256 / cpr;
+    const int col = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+    const int cc = col * 8;
+    const int Pq = N * Ho * Wo;
+    const int q0 = blockIdx.x * quads_per_block, q1 = min(Pq, q0 + quads_per_block);
+    float s1[8], s2[8], m[8], iv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+    if (rsub < rif) {
+        load8f(mean + cc, m); load8f(invstd + cc, iv);
+        for (int q = q0 + rsub; q < q1; q += rif) {
+            const int j = q % Wo, k = (q / Wo) % Ho, n = q / (Wo * Ho);
+            float g[4][8];
+            int av[4][8];
+            const bool vk = k + 1 < Ho, vj = j + 1 < Wo;
+#pragma unroll
+            for (int wdx = 0; wdx < 4; ++wdx) {
+                const int ho = min(k + (wdx >> 1), Ho - 1), wo = min(j + (wdx & 1), Wo - 1);
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + cc;
+                const uint2 a2 = *reinterpret_cast<const uint2*>(arg + o);
+                unpack8(*reinterpret_cast<const uint4*>(dp + o), g[wdx]);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) av[wdx][t] = (int)(((t < 4 ? (a2.x >> (8 * t)) : (a2.y >> (8 * (t - 4)))) & 0xff));
+            }
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    float dz[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) dz[t] = 0.f;
+#pragma unroll
+                    for (int wdx = 0; wdx < 4; ++wdx) {
+                        const int da = wdx >> 1, db = wdx & 1;
+                        if ((da && !pa) || (db && !pb)) continue;
+                        const bool ok = (!da || vk) && (!db || vj);
+                        const int tap = ok ? (da ? 0 : 1 + pa) * 3 + (db ? 0 : 1 + pb) : -1;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (av[wdx][t] == tap) dz[t] += g[wdx][t];
+                    }
+                    const size_t p = ((size_t)n * H + 2 * k + pa) * W + 2 * j + pb;
+                    float rv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(raw + p * C + cc), rv);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { s1[t] += dz[t]; s2[t] += dz[t] * ((rv[t] - m[t]) * iv[t]); }
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { red[((size_t)rsub * C + cc + t) * 2] = s1[t]; red[((size_t)rsub * C + cc + t) * 2 + 1] = s2[t]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * 2; e += 256) {
+        float sum = 0.f;
+        for (int r = 0; r < rif; ++r) sum += red[(size_t)r * C * 2 + e];
+        partial[(size_t)blockIdx.x * C * 2 + e] = sum;
+    }
+}
 // Apply pass on 2 x 2 pixel quads (H, W even): the four pixels of a quad draw on the same four pooling windows, so a thread loads each
 // (dp, arg) window once instead of once per pixel (the gather above re-reads every window four times: 400 MB of L2 traffic for a
 // 67 MB tensor).  Per pixel the windows are added in the same (ho, wo) order as maxpool_gather_dz: bit-identical results.
@@ -890,10 +954,14 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     const int P = N * H * W;
     if ((long long)P * (C / 8) >= (1ll << 32)) { set_error("maxpool_bn_bwd: more than 2^32 16-byte chunks"); return DALI_ERR_LIMIT; }
     int rpb;
-    const int blocks = bn_bwd_blocks(P, C, &rpb);
+    const bool quads = (H & 1) == 0 && (W & 1) == 0;
+    // (the partial buffer is sized for bn_bwd_blocks(P, C): the quad form needs at most as many rows)
+    const int blocks = quads ? bn_bwd_blocks(N * Ho * Wo, C, &rpb) : bn_bwd_blocks(P, C, &rpb);
     const int rif = 256 / (C / 8);
-    hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)rif * C * 2 * sizeof(float), st, dp, arg, raw, mean, invstd,
-                       N, H, W, C, Ho, Wo, rpb, partial);
+    if (quads) hipLaunchKernelGGL(maxpool_bn_bwd_reduce_quad_kernel, dim3(blocks), dim3(256), (size_t)rif * C * 2 * sizeof(float), st, dp, arg, raw, mean,
+                                  invstd, N, H, W, C, Ho, Wo, rpb, partial);
+    else hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)rif * C * 2 * sizeof(float), st, dp, arg, raw, mean, invstd,
+                            N, H, W, C, Ho, Wo, rpb, partial);
     DALI_LAUNCH_CHECK();
     int S, rc;
     if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
