@@ -218,7 +218,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 5] = __builtin_amdgcn_s_memrealtime();     // stats done
 
     // ---- lean path: plain convolution (optionally + residual), interior tile, natural output addressing ----
-    const bool plain = !a.bias && !a.O2 && a.act == 0 && !a.dact_pre && !a.g.sub && (a.Cm & 7) == 0;
+    const bool plain = !a.O2 && a.act == 0 && !a.dact_pre && !a.g.sub && (a.Cm & 7) == 0;      // bias (linear layers) is folded in below
     const bool interior = (tm + 1) * TM <= a.Cm && (tn + 1) * TN <= a.P;
     if (plain && interior) {
         constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
@@ -228,6 +228,10 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         char* my_stage = stage + (wn * WROWS + (lane & 15)) * ROWB + mb * 2;              // + jj*16*ROWB + i*32
         const int ch = threadIdx.x % CPR, lp0 = threadIdx.x / CPR;                        // read-out: 16-byte chunk / first row
         static_assert(ROWS * ROWB == STAGE_BYTES, "layout of the partial sums behind the staged tile");
+        float4 bias4[Cfg::FM];                                                            // this lane's 4 channels of every 16-row block
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i)
+            bias4[i] = a.bias ? *reinterpret_cast<const float4*>(a.bias + tm * TM + mb + i * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
@@ -251,7 +255,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 const int j = h * HFN + jj;
 #pragma unroll
                 for (int i = 0; i < Cfg::FM; ++i) {
-                    float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                    float v0 = acc[i][j][0] + bias4[i].x, v1 = acc[i][j][1] + bias4[i].y, v2 = acc[i][j][2] + bias4[i].z, v3 = acc[i][j][3] + bias4[i].w;
                     uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
                     if (a.Res) {
                         const uint2 rv = *slot;
