@@ -175,7 +175,7 @@ __device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, unsigned bits) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 1, 1) << 16;         // 0 or 0xffff0000
     return w & (lo | hi);
 }
-template <int TM, int TN, int FM_, int FN_, int WNW, int NT>
+template <int TM, int TN, int FM_, int FN_, int WNW, int NT, bool LIN = false>
 __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&acc)[FM_][FN_], int tm, int tn, uint16_t* smem, int wm, int wn) {
     using Cfg = EpiShape<FM_, FN_>;
     static_assert(FN_ % 2 == 0, "the staged store splits the tile's pixels in two halves");
@@ -219,6 +219,11 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
 
     // ---- lean path: plain convolution (optionally + residual), interior tile, natural output addressing ----
     const bool plain = !a.O2 && a.act == 0 && !a.dact_pre && !a.g.sub && (a.Cm & 7) == 0;      // bias (linear layers) is folded in below
+    // the linear layers' GELU / pre-activation copy (O2) / GELU' factor take a second staged block further down, kept apart so that the
+    // convolutions' path stays as lean as it was (folding them into one block cost the ResNet step 0.8 ms)
+    // (only in the LIN instantiations of the kernels: compiled into every kernel it changed the convolutions' register allocation and
+    // cost the ResNet step 0.4 ms even when never taken)
+    const bool plain_ext = LIN && !plain && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre);
     const bool interior = (tm + 1) * TM <= a.Cm && (tn + 1) * TN <= a.P;
     if (plain && interior) {
         constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
@@ -280,6 +285,94 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         return;
     }
 
+    if constexpr (LIN) if (plain_ext && interior) {            // linear-layer extras: GELU, pre-activation copy, GELU' factor
+        constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
+        constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
+        static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
+        char* stage = reinterpret_cast<char*>(smem);
+        char* my_stage = stage + (wn * WROWS + (lane & 15)) * ROWB + mb * 2;              // + jj*16*ROWB + i*32
+        const int ch = threadIdx.x % CPR, lp0 = threadIdx.x / CPR;                        // read-out: 16-byte chunk / first row
+        static_assert(ROWS * ROWB == STAGE_BYTES, "layout of the partial sums behind the staged tile");
+        float4 bias4[Cfg::FM];                                                            // this lane's 4 channels of every 16-row block
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i)
+            bias4[i] = a.bias ? *reinterpret_cast<const float4*>(a.bias + tm * TM + mb + i * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint16_t* in_tile = a.Res ? a.Res : a.dact_pre;       // optional input tile staged through LDS in the output layout
+        auto store_half = [&](uint16_t* dst, size_t gbase) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int lp = lp0 + it * (NT / CPR);
+                const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);                  // pixel inside the tile, minus h*WROWS
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + gbase + (size_t)q * a.Cm * 2) =
+                    *reinterpret_cast<const uint4*>(stage + lp * ROWB + ch * 16);
+            }
+        };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
+            if (a.O2) {                                         // pre-activation copy (kept for the backward) goes out first
+#pragma unroll
+                for (int jj = 0; jj < HFN; ++jj) {
+                    const int j = h * HFN + jj;
+#pragma unroll
+                    for (int i = 0; i < Cfg::FM; ++i)
+                        *reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32) =
+                            make_uint2(pack_bf16x2(acc[i][j][0] + bias4[i].x, acc[i][j][1] + bias4[i].y), pack_bf16x2(acc[i][j][2] + bias4[i].z, acc[i][j][3] + bias4[i].w));
+                }
+                lds_barrier();
+                store_half(a.O2, gbase);
+                lds_barrier();
+            }
+            if (in_tile) {                                      // residual / GELU' argument tile -> LDS with 16-byte loads
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lp = lp0 + it * (NT / CPR);
+                    const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
+                    const size_t rb = gbase + (size_t)q * a.Cm * 2;
+                    uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(in_tile) + rb);
+                    if (a.Res && a.res_mask) {                  // 16 bytes = 8 channels = one mask byte
+                        const unsigned m = a.res_mask[rb >> 4];
+                        rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
+                    }
+                    *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) = rv;
+                }
+                lds_barrier_vm();                               // the loaded tile is visible to every wave
+            }
+#pragma unroll
+            for (int jj = 0; jj < HFN; ++jj) {
+                const int j = h * HFN + jj;
+#pragma unroll
+                for (int i = 0; i < Cfg::FM; ++i) {
+                    float v[4] = {acc[i][j][0] + bias4[i].x, acc[i][j][1] + bias4[i].y, acc[i][j][2] + bias4[i].z, acc[i][j][3] + bias4[i].w};
+                    uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
+                    if (a.act == 1) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = 0.5f * v[t] * (1.0f + erff(v[t] * 0.70710678118654752f));
+                    }
+                    if (in_tile) {
+                        const uint2 rv = *slot;
+                        const float x4[4] = {bf16_bits_to_f32(rv.x & 0xffffu), bf16_bits_to_f32(rv.x >> 16), bf16_bits_to_f32(rv.y & 0xffffu), bf16_bits_to_f32(rv.y >> 16)};
+                        if (a.Res) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) v[t] += x4[t];
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                v[t] *= 0.5f * (1.0f + erff(x4[t] * 0.70710678118654752f)) + x4[t] * 0.3989422804014327f * expf(-0.5f * x4[t] * x4[t]);
+                        }
+                    }
+                    *slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            }
+            lds_barrier();
+            if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 6 + 2 * h] = __builtin_amdgcn_s_memrealtime();   // half staged
+            store_half(a.O, gbase);
+            if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 7 + 2 * h] = __builtin_amdgcn_s_memrealtime();   // half's stores issued
+            if (h == 0) lds_barrier();                          // the LDS reads are done before the second half overwrites them
+        }
+        return;
+    }
+
     // ---- general path: edge tiles, linear-layer epilogues (bias / GELU / GELU' / second output), parity sub-problems ----
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
@@ -322,10 +415,10 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         }
     }
 }
-template <class Cfg>
+template <class Cfg, bool LIN = false>
 __device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)[Cfg::FM][Cfg::FN], int tm, int tn, uint16_t* smem) {
     const int wave = threadIdx.x >> 6;
-    conv_epilogue_g<Cfg::TM, Cfg::TN, Cfg::FM, Cfg::FN, 2, 256>(a, acc, tm, tn, smem, wave >> 1, wave & 1);
+    conv_epilogue_g<Cfg::TM, Cfg::TN, Cfg::FM, Cfg::FN, 2, 256, LIN>(a, acc, tm, tn, smem, wave >> 1, wave & 1);
 }
 
 template <int TM, int TN, bool IN_BN>
@@ -359,7 +452,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
 // ------------------------------------------------------------------------------------------------
 // (lds_void_ptr, DMA_OOB, dma_wait<N> live in gemm_tile.h: shared with eval.hip)
 
-template <int TM, int TN, int NSTAGE>
+template <int TM, int TN, int NSTAGE, bool LIN = false>
 __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     // 128 x 128: <= 128 VGPRs (4 waves per SIMD); the 64 x 256 shape carries twice the per-lane gather state and would spill
     using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
@@ -483,7 +576,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kerne
     __syncthreads();
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
 
-    conv_epilogue<Cfg>(a, acc, tm, tn, smem);
+    conv_epilogue<Cfg, LIN>(a, acc, tm, tn, smem);
     if (a.stamps) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();   // all stores issued (not yet acknowledged)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have been acknowledged
@@ -498,7 +591,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kerne
 // budget as the 128 x 128 kernel), block tile (64*WM) x (64*WN).  256 x 256 with 16 waves halves the L2->LDS bytes per
 // FLOP (measured limiter of the 128 x 128 kernel: ~47 GB/s per CU of operand traffic at 0.8 PFLOP/s) and leaves room
 // for a 4-deep LDS ring (3 k-tiles in flight) at one block per CU.
-template <int WM, int WN, int NSTAGE>
+template <int WM, int WN, int NSTAGE, bool LIN = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN, NT = NW * 64;
     constexpr int A_BLK = TM / 16 / NW, B_BLK = TN / 16 / NW, NDMA = A_BLK + B_BLK;
@@ -611,7 +704,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
         st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
     }
     __syncthreads();
-    conv_epilogue_g<TM, TN, 4, 4, WN, NT>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, 4, 4, WN, NT, LIN>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -624,7 +717,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
 // logical chunk ^ ((row >> 1) & 7): every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ... = 8 rows of one
 // chunk + 8 rows of the next) lands on 16 distinct 16-byte bank slots.  Needs Ck % 64 == 0.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4>
+template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4, bool LIN = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NW = WM * WN, NT = NW * 64;     // per-wave sub-tile 16 FM x 16 FN
     constexpr int A_BLK = TM / 8 / NW, B_BLK = TN / 8 / NW, NDMA = A_BLK + B_BLK;
@@ -734,7 +827,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
         st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
     }
     __syncthreads();
-    conv_epilogue_g<TM, TN, FM, FN, WN, NT>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT, LIN>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // Wave-specialised k-tile-64 kernel: WM x WN consumer waves (64 x 64 sub-tiles: fragment reads + MFMAs + epilogue) and NP
@@ -742,7 +835,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
 // costs the issuing wave 60-185 cycles in which it cannot issue MFMAs, and the feed time added to the MFMA time instead of
 // hiding under it (ablations in scripts/ablate_conv.py, same finding and same cure as pairdist_dma_kernel in eval.hip).
 // The producers leave after the last k-step; the epilogue's barriers then count the consumers only.
-template <int WM, int WN, int NP, int NSTAGE, int FM = 4, int FN = 4>
+template <int WM, int WN, int NP, int NSTAGE, int FM = 4, int FN = 4, bool LIN = false>
 __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NC = WM * WN, NT = NC * 64;       // consumer sub-tile 16 FM x 16 FN
     constexpr int A_BLK = TM / 8 / NP, B_BLK = TN / 8 / NP, NDMA = A_BLK + B_BLK;
@@ -861,7 +954,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
         __builtin_amdgcn_s_barrier();
         st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
     }
-    conv_epilogue_g<TM, TN, FM, FN, WN, NT>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT, LIN>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1795,6 +1888,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     // k-tile 64 pays where the main loop dominates (K >= 1024); with a short K or the 128 x 128 tile the smaller k-tile's 2-3
     // co-resident workgroups overlap their epilogues better (measured per layer: 256 x 256 -12..-15 %; 128 x 256 wave-specialised
     // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
+    const bool lin = a.act != 0 || a.O2 != nullptr || a.dact_pre != nullptr;      // linear-layer epilogue extras: the LIN kernel instantiations
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
     const int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
     static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
@@ -1807,8 +1901,13 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         // (8 waves with 128 x 64 per wave, 25 % fewer LDS fragment bytes, 192 VGPRs: measured 3-5 % slower than 16 waves of 64 x 64)
         // and the wave-specialised form (8 consumers of 128 x 64 + 4 producers, 168 VGPRs, 2-stage ring): -2 % on layer4's 3x3, +14 % on
         // the stride-2 downsample dgrad -- a 256 x 256 tile has no room for producers beside 16 consumers (1024 threads per workgroup)
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
-        hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        if (lin) hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
@@ -1816,9 +1915,11 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         if (!attr_set) {
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr_set = true;
         }
         if (k64 == 6) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        else if (lin) hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128) {
         static bool attr_set = false;
@@ -1862,14 +1963,20 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
         const int lds = (128 + 256) * 32 * 2 * 3;
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
-        hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        if (lin) hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else {
         using Cfg = GemmCfg<128, 128, 1, 1, 1>;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<128, 128, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else if (dma_ok && conv_cfg_override() == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok && lin) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
     }
