@@ -175,7 +175,9 @@ __device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, unsigned bits) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 1, 1) << 16;         // 0 or 0xffff0000
     return w & (lo | hi);
 }
-template <int TM, int TN, int FM_, int FN_, int WNW, int NT, bool LIN = false>
+// LIN: 0 = a convolution-only instantiation (no linear-layer extras compiled in at all), 1 = extras in the staged block and in the
+// general path (the LIN kernel variants), 2 = extras in the general path only (kernels without a LIN variant)
+template <int TM, int TN, int FM_, int FN_, int WNW, int NT, int LIN = 2>
 __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&acc)[FM_][FN_], int tm, int tn, uint16_t* smem, int wm, int wn) {
     using Cfg = EpiShape<FM_, FN_>;
     static_assert(FN_ % 2 == 0, "the staged store splits the tile's pixels in two halves");
@@ -223,7 +225,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     // convolutions' path stays as lean as it was (folding them into one block cost the ResNet step 0.8 ms)
     // (only in the LIN instantiations of the kernels: compiled into every kernel it changed the convolutions' register allocation and
     // cost the ResNet step 0.4 ms even when never taken)
-    const bool plain_ext = LIN && !plain && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre);
+    const bool plain_ext = LIN == 1 && !plain && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre);
     const bool interior = (tm + 1) * TM <= a.Cm && (tn + 1) * TN <= a.P;
     if (plain && interior) {
         constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
@@ -285,7 +287,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         return;
     }
 
-    if constexpr (LIN) if (plain_ext && interior) {            // linear-layer extras: GELU, pre-activation copy, GELU' factor
+    if constexpr (LIN == 1) if (plain_ext && interior) {            // linear-layer extras: GELU, pre-activation copy, GELU' factor
         constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
         constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
         static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
@@ -388,6 +390,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
+                if constexpr (LIN != 0) {
                 if (a.O2) *reinterpret_cast<uint2*>(a.O2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 if (a.act == 1) {
 #pragma unroll
@@ -400,6 +403,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         v[t] *= 0.5f * (1.0f + erff(x4[t] * 0.70710678118654752f)) + x4[t] * 0.3989422804014327f * expf(-0.5f * x4[t] * x4[t]);
+                }
                 }
                 if (a.Res) {
                     uint2 rv = *reinterpret_cast<const uint2*>(a.Res + o);
@@ -415,7 +419,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         }
     }
 }
-template <class Cfg, bool LIN = false>
+template <class Cfg, int LIN = 2>
 __device__ __forceinline__ void conv_epilogue(const IGemmArgs& a, f32x4_t (&acc)[Cfg::FM][Cfg::FN], int tm, int tn, uint16_t* smem) {
     const int wave = threadIdx.x >> 6;
     conv_epilogue_g<Cfg::TM, Cfg::TN, Cfg::FM, Cfg::FN, 2, 256, LIN>(a, acc, tm, tn, smem, wave >> 1, wave & 1);
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kerne
     __syncthreads();
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
 
-    conv_epilogue<Cfg, LIN>(a, acc, tm, tn, smem);
+    conv_epilogue<Cfg, (TM == 128 && TN == 128 && NSTAGE == 3) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem);
     if (a.stamps) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();   // all stores issued (not yet acknowledged)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have been acknowledged
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
         st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
     }
     __syncthreads();
-    conv_epilogue_g<TM, TN, 4, 4, WN, NT, LIN>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, 4, 4, WN, NT, (WM == 2 && WN == 4 && NSTAGE == 3) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
         st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
     }
     __syncthreads();
-    conv_epilogue_g<TM, TN, FM, FN, WN, NT, LIN>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 4 && WN == 4 && NSTAGE == 2 && FM == 4) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // Wave-specialised k-tile-64 kernel: WM x WN consumer waves (64 x 64 sub-tiles: fragment reads + MFMAs + epilogue) and NP
@@ -954,7 +958,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
         __builtin_amdgcn_s_barrier();
         st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
     }
-    conv_epilogue_g<TM, TN, FM, FN, WN, NT, LIN>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 2 && WN == 4 && NP == 8 && NSTAGE == 3) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
