@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the DaliID Person-ReID hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload train|distance]
+    python bench.py --gpus N --steps K --warmup W [--workload train|vit|distance]
 
 Prints ONE JSON line (rank 0).  Workloads (BASELINE.json):
   * train    (configs[1]): ResNet-50 ReID bf16, PK batch 16x16=256 per GPU, center + proxy heads, Adam, EMA;
                metric images/sec; data-parallel over N GPUs with RCCL gradient all-reduce (weak scaling).
+               The default run also carries the other half of BASELINE.json's metric as a ``"distance"`` sub-record
+               (configs[4], below) unless --no-distance is given.
   * distance (configs[4]): 10k x 100k x 2048 cosine distmat (+ CMC/mAP timed separately); metric Gpairs/sec.
+  * vit      (configs[3]): TransReID ViT-B/16 train step, batch 128 per GPU.
 Inputs are synthetic and resident in HBM before the timed region.
+
+``--gpus N`` with N > 1: when no launcher has set WORLD_SIZE, this process starts N ranks itself
+(``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a CHILD process, before anything here touches a
+GPU), relays rank 0's JSON line and exits with the launcher's status.  Under an outer ``torch.distributed.run`` it is
+a rank and reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,18 +35,77 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 
 
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: start N ranks as a child process group and relay rank 0's line.  Nothing in this
+    process has touched a GPU yet (``torch.cuda.device_count()`` does not initialise HIP), and the ranks are CHILD
+    processes, never an exec of this one."""
+    n_dev = torch.cuda.device_count()
+    if 0 < n_dev < args.gpus:
+        print(json.dumps({"error": "--gpus %d but only %d GPUs are visible" % (args.gpus, n_dev), "n_gpus": args.gpus}))
+        return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL across processes)
+    env["DALIID_BENCH_CHILD"] = "1"
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    log("self-launch: %s" % " ".join(cmd))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"n_gpus"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+        if rc == 0 and '"error"' in line:
+            rc = 3
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def dist_setup(n_gpus):
+    """-> (world, rank, local, backend).  world > 1 on a GPU box: backend "nccl" (= RCCL over xGMI), one rank per GPU.
+    Without a GPU (the build container) the ranks still form a gloo group so that the launch path itself is testable;
+    the workloads then refuse to run (there is no CPU path)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or leave "
+                         "WORLD_SIZE unset and bench.py starts the ranks itself)" % (n_gpus, world, n_gpus))
+    have_gpu = torch.cuda.device_count() > 0
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
+        if have_gpu:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            backend = "nccl"
+        else:
+            dist.init_process_group("gloo")
+            backend = "gloo"
+    elif have_gpu:
         torch.cuda.set_device(0)
-    assert world == n_gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (n_gpus, world)
-    return world, rank, local
+    return world, rank, local, backend
+
+
+def cpu_guard_line(args, world, rank, backend):
+    """No GPU here: prove the launch path (N ranks, process group, one all-reduce) and say so in the line."""
+    seen = world
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+    return {"error": "no GPU visible: daliid_amd has no CPU path; launch path only", "n_gpus": world, "world_size_seen": seen,
+            "backend": backend, "steps": args.steps, "warmup": args.warmup}
 
 
 def barrier_sync(world):
@@ -87,10 +157,14 @@ def bench_distance(args, world, rank):
     k_ms = ev[0].elapsed_time(ev[1]) / args.steps
     flops = 2.0 * d * nq * ng
     achieved = flops / (k_ms * 1e-3) / 1e12
-    roofline = {"kernel": "pairdist_dma_kernel<%d>" % (3 if prec == "bf16x3" else 1), "bound": "mfma",
+    nprod = 3 if prec == "bf16x3" else 1
+    roofline = {"kernel": "pairdist_dma_kernel<%d>" % nprod, "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel_ms": round(k_ms, 4), "mfma_issue_multiplier": 3 if prec == "bf16x3" else 1}
+                "kernel_ms": round(k_ms, 4), "mfma_issue_multiplier": nprod,
+                "issue_frac": round(nprod * achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                "note": "achieved = 2*D FLOP per pair (algorithmic) / kernel time; bf16x3 issues 3 bf16 MFMA products per algorithmic "
+                        "product (hi*hi + hi*lo + lo*hi) for fp32-grade results, issue_frac = MFMA issue rate / dense bf16 peak"}
 
     # ranking (CMC/mAP) timed separately
     import numpy as np
@@ -110,26 +184,51 @@ def bench_distance(args, world, rank):
     torch.cuda.synchronize()
     rank_ms = ev[0].elapsed_time(ev[1]) / args.steps
 
+    del out, q, g, qp, gp
+    torch.cuda.empty_cache()
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline_distance()
     return {"metric": "gallery-distance Gpairs/sec", "value": round(gpairs, 3), "unit": "Gpairs/s",
             "ms_per_step": round(ms_step, 4), "dtype": "bf16" if prec == "bf16" else "bf16x3(fp32-grade)",
             "config": {"workload": "configs[4]: 10k x 100k x 2048 cosine distmat, normalise fused; per GPU",
-                       "nq": nq, "ng": ng, "d": d, "precision": prec, "rank_eval_ms": round(rank_ms, 3), "rank_eval_GBps": round(nq * ng * 4 / 1e9 / (rank_ms * 1e-3), 1),
-                       "mAP_on_random_features": round(float(mAP), 6)},
+                       "nq": nq, "ng": ng, "d": d, "precision": prec, "mAP_on_random_features": round(float(mAP), 6)},
+            "rank_eval_ms": round(rank_ms, 3), "rank_eval_GBps": round(nq * ng * 4 / 1e9 / (rank_ms * 1e-3), 1),
+            "rank_eval_hbm_frac": round(nq * ng * 4 / 1e9 / (rank_ms * 1e-3) / HBM_PEAK_GBS, 4),
             "roofline": roofline, "cpu_baseline": cpu}
 
 
+def kernel_source_hash():
+    """sha1 over the HIP kernel sources: ties a committed PMC profile to the code it was measured on (.git does not travel
+    to the GPU box, so a commit id cannot be read there)."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "daliid_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic(which):
-    """HBM bytes per step of the GEMM kernels from the committed PMC pass (profiles/*_pmc_traffic.json: rocprofv3 --pmc
-    in its own run, corrected as MI355X_MICROARCH.md prescribes); None when no such profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % which)
-    try:
-        with open(path) as f:
-            return json.load(f)["gemm_kernels_hbm_bytes_per_step"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per step of the GEMM kernels from the committed PMC pass (profiles/*_pmc_traffic.json: rocprofv3 --pmc in
+    its own run, corrected as MI355X_MICROARCH.md prescribes).  -> (bytes or None, provenance string).  The number is NOT
+    measured in this run; it is reported only while the kernel sources still hash to what the profile was taken on."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, which))
+        try:
+            with open(path) as f:
+                j = json.load(f)
+            val = j["gemm_kernels_hbm_bytes_per_step"]
+        except (OSError, KeyError, ValueError):
+            continue
+        want, have = j.get("kernel_source_hash"), kernel_source_hash()
+        rel = os.path.relpath(path, ROOT)
+        if want is None:
+            return None, "%s carries no kernel_source_hash (taken before the kernels were last changed): not reported" % rel
+        if want != have:
+            return None, "%s was taken on kernel sources %s, this tree is %s: not reported" % (rel, want, have)
+        return val, "committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs; kernel sources %s)" % (rel, have)
+    return None, "no committed PMC profile"
 
 
 def log(msg):
@@ -291,10 +390,10 @@ def bench_train(args, world, rank):
     k_launches = sum(gp.launches) // psteps
     alg_flops = batch * gflop_img * 1e9
     tflops = alg_flops / (k_ms * 1e-3) / 1e12
-    traffic = committed_traffic("vit" if vit else "train")
+    traffic, traffic_source = committed_traffic("vit" if vit else "train")
     roofline = {"kernel": "igemm_conv_* + igemm_wgrad_* (implicit-GEMM MFMA kernels%s)" % ("; attention kernels not included" if vit else ""),
                 "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches_per_step": int(k_launches), "kernel_ms_per_step": round(k_ms, 3),
                 "avg_launch_us": round(k_ms * 1e3 / max(k_launches, 1), 2),
                 "by_class_ms_per_step": {"conv_fwd_dgrad": round(gp.ms[0] / psteps, 3), "wgrad": round(gp.ms[1] / psteps, 3)},
@@ -306,6 +405,9 @@ def bench_train(args, world, rank):
                         "entire step (BatchNorm, pools, heads, Adam, EMA included)" % (gflop_img, batch)}
     final = acc.cpu().numpy()
     log("GPU: %.3f ms/step (device %.3f ms), %.1f images/s" % (ms_step, gpu_ms, ips))
+    comm = None
+    if world > 1:
+        comm = allreduce_probe(tr, world, args.steps)
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and not vit:
         cpu = cpu_baseline_train()
@@ -315,7 +417,34 @@ def bench_train(args, world, rank):
             "dtype": "bf16", "config": {"workload": wl + ("; data-parallel, RCCL all-reduce of gradients" if world > 1 else ""),
                                         "global_batch": world * batch, "per_gpu_batch": batch, "parallelism": "dp%d" % world,
                                         "mean_loss": float(final[2] / max(final[4], 1))},
-            "roofline": roofline, "cpu_baseline": cpu}
+            "roofline": roofline, "cpu_baseline": cpu, "comm": comm}
+
+
+def allreduce_probe(tr, world, steps):
+    """The gradient all-reduce of one step alone (all stage buckets back to back on the reducer's stream, nothing to overlap
+    with): ms per step and bus bandwidth, so that the scaling curve can be read against the collective's own cost."""
+    import torch.distributed as dist
+    dp = tr._dp
+    if dp is None:
+        return None
+    n_bytes = sum(max(e - b, 0) for b, e in dp.ranges) * 4
+    def one():
+        for s in range(len(dp.ranges)):
+            dp.reduce_stage(s)
+        dp.finish()
+    one(); barrier_sync(world)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        one()
+    ev1.record()
+    barrier_sync(world)
+    ms = max_over_ranks(ev0.elapsed_time(ev1) / steps, world)
+    return {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "buckets": len(dp.ranges), "bytes_per_step": n_bytes,
+            "allreduce_ms_per_step": round(ms, 3),
+            "bus_GBps": round(2.0 * (world - 1) / world * n_bytes / 1e9 / (ms * 1e-3), 1),
+            "note": "standalone (un-overlapped) SUM all-reduce of the flat fp32 gradient buffer in its per-stage buckets; in the timed "
+                    "step the buckets run on a side stream under the remaining backward"}
 
 
 def cpu_baseline_train():
@@ -359,13 +488,36 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 256 for train, 128 for vit)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-distance", action="store_true", help="train workload: skip the configs[4] distance sub-record")
     args = ap.parse_args()
-    world, rank, local = dist_setup(args.gpus)
-    res = bench_distance(args, world, rank) if args.workload == "distance" else bench_train(args, world, rank)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    world, rank, local, backend = dist_setup(args.gpus)
+    if torch.cuda.device_count() == 0:
+        res = cpu_guard_line(args, world, rank, backend)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        sys.exit(0 if os.environ.get("DALIID_BENCH_CHILD") else 3)      # the self-launching parent turns the error line into status 3
+    if args.workload == "distance":
+        res = bench_distance(args, world, rank)
+    else:
+        res = bench_train(args, world, rank)
+        if args.workload == "train" and not args.no_distance:
+            # the other half of BASELINE.json's metric in the same line: configs[4] on every rank's own synthetic gallery
+            # (weak scaling: the gallery shards over ranks with no exchange)
+            d = bench_distance(args, world, rank)
+            d.pop("metric")
+            res["distance"] = d
     res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+    if world > 1:
+        res["world_size_seen"] = world
+        res["backend"] = backend
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

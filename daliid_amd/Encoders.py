@@ -229,8 +229,10 @@ class ResNet50ReID(nn.Module):
             self._bwd_plan = plan
         return emb
 
+    n_bwd_stages = 4          # 0: neck + head + layer4, 1: layer3, 2: layer2, 3: layer1 + stem (dali_resnet_backward)
+
     def _run_backward(self, d_emb):
-        for stage in range(4):
+        for stage in range(self.n_bwd_stages):
             self._backward_stage(d_emb, stage)
         self.attach_grads()
 

@@ -97,6 +97,10 @@ _SIGNATURES = {
     "dali_vit_refresh_weights": [c_void_p, c_void_p],
     "dali_vit_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "dali_vit_backward": [c_void_p, c_void_p, c_void_p],
+    "dali_vit_num_stages": [c_void_p],
+    "dali_vit_stage_param_range": [c_void_p, c_int, c_void_p, c_void_p],
+    "dali_vit_backward_stages": [c_void_p, c_void_p, c_void_p, c_int, c_int],
+    "dali_vit_set_drop_path": [c_void_p, c_void_p],
 }
 _RESTYPES = {"dali_last_error": ctypes.c_char_p, "dali_pairdist_operand_bytes": ctypes.c_size_t}
 

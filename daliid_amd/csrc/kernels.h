@@ -117,6 +117,9 @@ int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, c
                          const float* g32 = nullptr);
 size_t colsum_partial_floats(int rows, int C);
 int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out, float* partial, double* scratch);
+// out = (res or 0) + scale[row / rows_per_sample] * branch   (DropPath per sample; C % 8 == 0)
+int launch_rowscale_add(hipStream_t st, const uint16_t* branch, const float* scale, int samples, int rows_per_sample, int C, const uint16_t* res,
+                        uint16_t* out);
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse);
 int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
                          float scale, uint16_t* dqkv);

@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
     s1 = bn1d_slice_sum(s1, red);
     s2 = bn1d_slice_sum(s2, red);
     if (!ok) return;
-    if (ry == 0) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }
+    if (ry == 0) { dgamma[c] = (float)s2; if (dbeta) dbeta[c] = (float)s1; }       // dbeta null: frozen bias (make_models.py:181)
     const float a = (float)(s1 / N), b = (float)(s2 / N), sc = gamma[c] * iv;
     for (int n = ry; n < N; n += 8) {
         const float xh = (x[(size_t)n * C + c] - m) * iv;

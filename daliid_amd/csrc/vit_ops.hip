@@ -265,7 +265,8 @@ __global__ void finish_sum_kernel(const double* __restrict__ scratch, int S, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Multi-head self-attention, one 256-thread block per (batch, head); T <= 208 tokens, head_dim 64.
+// Multi-head self-attention, one block per (batch, head); head_dim 64; T <= 16 * NTILE tokens, NTILE in {13, 14, 16}
+// (197 tokens = ViT-B/16 at 224x224; 211 = TransReID's 256x128 at stride 12, vit_pytorch.py:254-267; up to 256).
 // qkv [B*T][3C] bf16 (q | k | v, head h at columns h*64 of each third, as vit_pytorch.py:155 lays them out).
 // Forward: O = softmax(Q K^T * scale) V, scores never leave the chip.  Per wave: 16 query rows at a time:
 //   S (16 x Tp) by MFMA from LDS-resident Q, K  ->  row softmax in registers  ->  P (bf16) through a per-wave LDS
@@ -274,7 +275,13 @@ __global__ void finish_sum_kernel(const double* __restrict__ scratch, int S, int
 // LDS images are plain row-major [Tp][72] bf16 (64 + 8 pad): both the K-contiguous (ds_read_b128) and the transposing
 // (tr_b16) fragment reads work on it.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_TP = 208, ATT_LD = 72, ATT_PK = 224, ATT_HD = 64, ATT_FWD_NW = 13, ATT_SW = 128;   // ATT_SW: columns of a half strip
+constexpr int ATT_LD = 72, ATT_HD = 64, ATT_SW = 128;   // ATT_SW: columns of a half strip
+constexpr int ATT_MAX_T = 256;
+// geometry of an NTILE-tile instance: TP = token rows of the images, second strip half = tiles 8 .. 8 + H2 - 1 (H2 even: whole
+// k-steps of 32 keys; tiles >= NTILE are zero), PK = rows the transposing reads of the P V / dS K loops may touch
+template <int NTILE> struct AttGeom {
+    static constexpr int TP = NTILE * 16, H2 = (NTILE - 8 + 1) / 2 * 2, PK = (8 + H2) * 16;
+};
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef short s16x8v __attribute__((ext_vector_type(8)));
 
@@ -293,9 +300,10 @@ __device__ __forceinline__ bf16x8_t frag_tr(const uint16_t* base, int ld, int k0
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+template <int TP>
 __device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, size_t row_stride, int T, uint16_t* dst) {
-    // [T][64] bf16 from global (row stride in elements) -> LDS [ATT_TP][ATT_LD], rows >= T zeroed
-    for (int i = threadIdx.x; i < ATT_TP * 8; i += blockDim.x) {
+    // [T][64] bf16 from global (row stride in elements) -> LDS [TP][ATT_LD], rows >= T zeroed
+    for (int i = threadIdx.x; i < TP * 8; i += blockDim.x) {
         const int row = i >> 3, ch = i & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < T) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
@@ -303,22 +311,25 @@ __device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, 
     }
 }
 
-// ATT_FWD_NW = 13 waves per (batch, head): one query tile per wave (4 waves: 4 rounds, 134 us per layer; 8 waves: 89 us).  A wave's P
-// strip holds half of the keys at a time ([16][128] bf16: tiles 0..7, then tiles 8..12 + one zero tile), so 13 strips fit beside Q, K, V.
-__global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
+// NW waves per (batch, head), one query tile per wave where the LDS allows (13 waves at 197 tokens; 4 waves: 4 rounds, 134 us per
+// layer; 8 waves: 89 us).  A wave's P strip holds half of the keys at a time ([16][128] bf16: tiles 0..7, then tiles 8..8+H2-1), so
+// the strips fit beside Q, K, V.
+template <int NTILE, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
                                                              uint16_t* __restrict__ out, float* __restrict__ lse) {
+    constexpr int ATT_TP = AttGeom<NTILE>::TP, ATT_PK = AttGeom<NTILE>::PK, H2 = AttGeom<NTILE>::H2, ATT_FWD_NW = NW;
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     uint16_t* sQ = sm;
     uint16_t* sK = sQ + ATT_TP * ATT_LD;
     uint16_t* sV = sK + ATT_TP * ATT_LD;
-    uint16_t* sP = sV + (ATT_PK) * ATT_LD;                         // V padded to 224 rows (zero) for the k loop of P V
+    uint16_t* sP = sV + (ATT_PK) * ATT_LD;                         // V padded to PK rows (zero) for the k loop of P V
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t rs = (size_t)3 * C;
     const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
-    att_load_tile(base, rs, T, sQ);
-    att_load_tile(base + C, rs, T, sK);
-    att_load_tile(base + 2 * C, rs, T, sV);
+    att_load_tile<ATT_TP>(base, rs, T, sQ);
+    att_load_tile<ATT_TP>(base + C, rs, T, sK);
+    att_load_tile<ATT_TP>(base + 2 * C, rs, T, sV);
     for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += ATT_FWD_NW * 64) sV[ATT_TP * ATT_LD + i] = 0;
     __syncthreads();
     uint16_t* myP = sP + wave * 16 * ATT_SW;
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const ui
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int jj = 0; jj < (hf == 0 ? 8 : 6); ++jj) {
+            for (int jj = 0; jj < (hf == 0 ? 8 : H2); ++jj) {
                 const int j = hf * 8 + jj;
                 uint2 pv = make_uint2(0u, 0u);
                 if (j < ATT_TP / 16) pv = make_uint2(pack_bf16x2(s[j < ATT_TP / 16 ? j : 0][0] * inv_l, s[j < ATT_TP / 16 ? j : 0][1] * inv_l),
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const ui
                 *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = pv;
             }
 #pragma unroll
-            for (int kk = 0; kk < (hf == 0 ? 4 : 3); ++kk) {
+            for (int kk = 0; kk < (hf == 0 ? 4 : H2 / 2); ++kk) {
                 const bf16x8_t pa = frag_k(myP, ATT_SW, 0, kk * 32, lane);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(sV, ATT_LD, hf * 128 + kk * 32, d * 16, lane), o[d], 0, 0, 0);
@@ -389,11 +400,13 @@ __global__ __launch_bounds__(ATT_FWD_NW * 64) void attention_fwd_kernel(const ui
 // 8 waves per (batch, head): 13 query / key tiles in 2 rounds instead of 4.  Four [224][72] images leave 32 KiB for the strips,
 // so a wave's strip holds HALF of the keys (queries) at a time: [16][128] bf16, tiles 0..7 then tiles 8..12 (+ one zero tile),
 // each half followed by its share of the second GEMM (4 resp. 3 k-steps of 32).
-constexpr int ATT_BWD_NW = 8;
-__global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+// (beyond 224 tokens the four [256][72] images leave room for 3 strips only: a 3-wave instance, slow but complete)
+template <int NTILE, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                                         const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                         int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
-    constexpr int NT = ATT_BWD_NW * 64, NTILE = ATT_TP / 16;       // 13 tiles of 16
+    constexpr int ATT_TP = AttGeom<NTILE>::TP, ATT_PK = AttGeom<NTILE>::PK, H2 = AttGeom<NTILE>::H2, ATT_BWD_NW = NW;
+    constexpr int NT = ATT_BWD_NW * 64;
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     uint16_t* sQ = sm;
     uint16_t* sK = sQ + ATT_PK * ATT_LD;
@@ -406,10 +419,10 @@ __global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const ui
     const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t rs = (size_t)3 * C;
     const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
-    att_load_tile(base, rs, T, sQ);
-    att_load_tile(base + C, rs, T, sK);
-    att_load_tile(base + 2 * C, rs, T, sV);
-    att_load_tile(d_o + (size_t)b * T * C + h * ATT_HD, C, T, sD);
+    att_load_tile<ATT_TP>(base, rs, T, sQ);
+    att_load_tile<ATT_TP>(base + C, rs, T, sK);
+    att_load_tile<ATT_TP>(base + 2 * C, rs, T, sV);
+    att_load_tile<ATT_TP>(d_o + (size_t)b * T * C + h * ATT_HD, C, T, sD);
     for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += NT) {
         sQ[ATT_TP * ATT_LD + i] = 0; sK[ATT_TP * ATT_LD + i] = 0; sV[ATT_TP * ATT_LD + i] = 0; sD[ATT_TP * ATT_LD + i] = 0;
     }
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const ui
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int jj = 0; jj < (hf == 0 ? 8 : 6); ++jj) {        // second half: tiles 8..12 and one zero tile (keys 208..223)
+            for (int jj = 0; jj < (hf == 0 ? 8 : H2); ++jj) {       // second half: tiles 8..NTILE-1 (+ a zero tile when NTILE is odd)
                 const int j = hf * 8 + jj;
                 const int key0 = j * 16 + (lane >> 4) * 4;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const ui
                 *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
 #pragma unroll
-            for (int kk = 0; kk < (hf == 0 ? 4 : 3); ++kk) {
+            for (int kk = 0; kk < (hf == 0 ? 4 : H2 / 2); ++kk) {
                 const bf16x8_t da = frag_k(myP, ATT_SW, 0, kk * 32, lane);
 #pragma unroll
                 for (int d = 0; d < 4; ++d)
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const ui
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-                for (int jj = 0; jj < (hf == 0 ? 8 : 6); ++jj) {    // query tile j = 8 hf + jj
+                for (int jj = 0; jj < (hf == 0 ? 8 : H2); ++jj) {   // query tile j = 8 hf + jj
                     const int j = hf * 8 + jj;
                     const int q0 = j * 16 + (lane >> 4) * 4;       // first of this lane's 4 queries
                     float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const ui
                     *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
 #pragma unroll
-                for (int kk = 0; kk < (hf == 0 ? 4 : 3); ++kk) {
+                for (int kk = 0; kk < (hf == 0 ? 4 : H2 / 2); ++kk) {
                     const bf16x8_t a = frag_k(myP, ATT_SW, 0, kk * 32, lane);
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -536,6 +549,25 @@ __global__ __launch_bounds__(ATT_BWD_NW * 64) void attention_bwd_kernel(const ui
                     dq_base[(size_t)key * rs + 2 * C + d * 16 + (lane & 15)] = f32_to_bf16_bits(dv[d][r]);
                 }
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DropPath (stochastic depth per sample, vit_pytorch.py:45-62): out[b][t][:] = (res ? res : 0) + scale[b] * branch[b][t][:],
+// scale[b] in {0, 1/keep_prob} drawn by the caller.  8 bf16 per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowscale_add_kernel(const uint16_t* __restrict__ branch, const float* __restrict__ scale, int rows_per_sample,
+                                                            int C, size_t chunks, const uint16_t* __restrict__ res, uint16_t* __restrict__ out) {
+    const int cpr = C / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / cpr;
+        const float sc = scale[row / rows_per_sample];
+        float v[8], r[8];
+        unpack8v(*reinterpret_cast<const uint4*>(branch + i * 8), v);
+        if (res) unpack8v(*reinterpret_cast<const uint4*>(res + i * 8), r);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = (res ? r[t] : 0.f) + sc * v[t];
+        *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
     }
 }
 
@@ -559,6 +591,13 @@ int launch_assemble_tokens(hipStream_t st, const uint16_t* pe, const float* cls,
 }
 int launch_assemble_tokens_bwd(hipStream_t st, const uint16_t* dx, int B, int T, int C, float* dpos, float* dcls, uint16_t* dpe) {
     hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3((T * (C / 8) + 255) / 256), dim3(256), 0, st, dx, B, T, C, dpos, dcls, dpe);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_rowscale_add(hipStream_t st, const uint16_t* branch, const float* scale, int samples, int rows_per_sample, int C, const uint16_t* res,
+                        uint16_t* out) {
+    const size_t chunks = (size_t)samples * rows_per_sample * (C / 8);
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3(vgrid(chunks, 4096)), dim3(256), 0, st, branch, scale, rows_per_sample, C, chunks, res, out);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -612,20 +651,46 @@ int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-constexpr size_t ATT_FWD_LDS = ((size_t)2 * ATT_TP * ATT_LD + (size_t)ATT_PK * ATT_LD + ATT_FWD_NW * 16 * ATT_SW) * 2;
-constexpr size_t ATT_BWD_LDS = ((size_t)4 * ATT_PK * ATT_LD + ATT_BWD_NW * 16 * ATT_SW) * 2 + 2 * ATT_PK * 4;
-int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
-    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_FWD_LDS));
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(ATT_FWD_NW * 64), ATT_FWD_LDS, st, qkv, B, T, H, scale, out, lse);
+template <int NTILE, int NW> constexpr size_t att_fwd_lds() {
+    return ((size_t)2 * AttGeom<NTILE>::TP * ATT_LD + (size_t)AttGeom<NTILE>::PK * ATT_LD + NW * 16 * ATT_SW) * 2;
+}
+template <int NTILE, int NW> constexpr size_t att_bwd_lds() {
+    return ((size_t)4 * AttGeom<NTILE>::PK * ATT_LD + NW * 16 * ATT_SW) * 2 + 2 * AttGeom<NTILE>::PK * 4;
+}
+static_assert(att_fwd_lds<13, 13>() <= 163840 && att_fwd_lds<14, 14>() <= 163840 && att_fwd_lds<16, 12>() <= 163840, "attention forward LDS");
+static_assert(att_bwd_lds<13, 8>() <= 163840 && att_bwd_lds<14, 8>() <= 163840 && att_bwd_lds<16, 3>() <= 163840, "attention backward LDS");
+
+template <int NTILE, int NW>
+static int att_fwd_launch(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
+    constexpr size_t lds = att_fwd_lds<NTILE, NW>();
+    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel<NTILE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attention_fwd_kernel<NTILE, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, B, T, H, scale, out, lse);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
-                         float scale, uint16_t* dqkv) {
-    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_BWD_LDS));
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(ATT_BWD_NW * 64), ATT_BWD_LDS, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+template <int NTILE, int NW>
+static int att_bwd_launch(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
+                          float scale, uint16_t* dqkv) {
+    constexpr size_t lds = att_bwd_lds<NTILE, NW>();
+    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<NTILE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attention_bwd_kernel<NTILE, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
+}
+int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
+    if (T <= 208) return att_fwd_launch<13, 13>(st, qkv, B, T, H, scale, out, lse);
+    if (T <= 224) return att_fwd_launch<14, 14>(st, qkv, B, T, H, scale, out, lse);
+    if (T <= 256) return att_fwd_launch<16, 12>(st, qkv, B, T, H, scale, out, lse);
+    set_error("attention: %d tokens exceed the limit of %d", T, ATT_MAX_T);
+    return DALI_ERR_LIMIT;
+}
+int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
+                         float scale, uint16_t* dqkv) {
+    if (T <= 208) return att_bwd_launch<13, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    if (T <= 224) return att_bwd_launch<14, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    if (T <= 256) return att_bwd_launch<16, 3>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    set_error("attention: %d tokens exceed the limit of %d", T, ATT_MAX_T);
+    return DALI_ERR_LIMIT;
 }
 
 }  // namespace dali
@@ -667,12 +732,12 @@ extern "C" int dali_layernorm_bwd(dali_ctx* ctx, void* stream, const uint16_t* g
 extern "C" int dali_attention_fwd(dali_ctx* ctx, void* stream, const uint16_t* qkv, int B, int T, int H, int head_dim, float scale,
                                   uint16_t* out, float* lse) {
     DALI_REQUIRE(ctx && qkv && out, "dali_attention_fwd: null argument");
-    DALI_REQUIRE(head_dim == ATT_HD && T > 0 && T <= ATT_TP, "dali_attention_fwd: head_dim must be %d and T <= %d (got %d, %d)", ATT_HD, ATT_TP, head_dim, T);
+    DALI_REQUIRE(head_dim == ATT_HD && T > 0 && T <= ATT_MAX_T, "dali_attention_fwd: head_dim must be %d and T <= %d (got %d, %d)", ATT_HD, ATT_MAX_T, head_dim, T);
     return launch_attention_fwd((hipStream_t)stream, qkv, B, T, H, scale, out, lse);
 }
 extern "C" int dali_attention_bwd(dali_ctx* ctx, void* stream, const uint16_t* qkv, const uint16_t* out, const uint16_t* d_out, const float* lse,
                                   int B, int T, int H, int head_dim, float scale, uint16_t* dqkv) {
     DALI_REQUIRE(ctx && qkv && out && d_out && lse && dqkv, "dali_attention_bwd: null argument");
-    DALI_REQUIRE(head_dim == ATT_HD && T > 0 && T <= ATT_TP, "dali_attention_bwd: head_dim must be %d and T <= %d", ATT_HD, ATT_TP);
+    DALI_REQUIRE(head_dim == ATT_HD && T > 0 && T <= ATT_MAX_T, "dali_attention_bwd: head_dim must be %d and T <= %d", ATT_HD, ATT_MAX_T);
     return launch_attention_bwd((hipStream_t)stream, qkv, out, d_out, lse, B, T, H, scale, dqkv);
 }

@@ -1,6 +1,7 @@
 // vit_plan.hip -- native executor of the TransReID ViT encoder + BN neck:
 //   make_models.build_transformer.forward (make_models.py:184-205) over vit_pytorch.TransReID.forward_features
-//   (vit_pytorch.py:375-408; camera = view = 0, local_feature = False; DropPath / Dropout rate 0 -- SURVEY K26).
+//   (vit_pytorch.py:375-408; camera = view = 0, local_feature = False; Dropout rate 0).  DropPath (vit_pytorch.py:45-62, wired at
+//   :338 and :178-179) is applied in training when the caller hands over the per-sample branch scales (dali_vit_set_drop_path).
 // Same contract as resnet_plan.hip: the plan owns topology + launch order, PyTorch owns flat fp32 params / grads /
 // buffers and one byte arena.  Parameter names / order follow the reference state_dict ("base.cls_token",
 // "base.pos_embed", "base.patch_embed.proj.weight", "base.blocks.N....", "base.norm.*", "base.fc.*", "bottleneck.*").
@@ -44,6 +45,10 @@ struct dali_vit {
     float *P = nullptr, *G = nullptr, *Bf = nullptr;
     char* arena = nullptr;
     bool fwd_training = false;
+    const float* dp_scale = nullptr;      // device [2*depth][B]: row 2i = attention branch of block i, 2i+1 = its MLP branch; null = no DropPath
+    const float* dp_used = nullptr;       // what the last training forward applied (the backward mirrors it)
+    int n_stages = 1;
+    std::vector<int> stage_first_block;   // backward stage s runs blocks [stage_first_block[s+1], stage_first_block[s]) downwards
 };
 
 namespace {
@@ -80,7 +85,7 @@ extern "C" int dali_vit_create(dali_ctx* ctx, const dali_vit_cfg* cfg, dali_vit*
     n->ctx = ctx; n->cfg = *cfg;
     const int ny = (cfg->height - cfg->patch) / cfg->stride + 1, nx = (cfg->width - cfg->patch) / cfg->stride + 1;
     n->B = cfg->batch; n->np = ny * nx; n->T = n->np + 1; n->C = cfg->dim; n->H = cfg->heads; n->rows = n->B * n->T;
-    if (n->T > 208) { set_error("dali_vit_create: %d tokens exceed the attention kernel's limit of 208", n->T); delete n; return DALI_ERR_LIMIT; }
+    if (n->T > 256) { set_error("dali_vit_create: %d tokens exceed the attention kernel's limit of 256", n->T); delete n; return DALI_ERR_LIMIT; }
     const int C = n->C, Kp = 3 * cfg->patch * cfg->patch;
     n->cls_off = addt(n->params, n->param_elems, "base.cls_token", {1, 1, C});
     n->pos_off = addt(n->params, n->param_elems, "base.pos_embed", {1, n->T, C});
@@ -105,6 +110,10 @@ extern "C" int dali_vit_create(dali_ctx* ctx, const dali_vit_cfg* cfg, dali_vit*
     n->neck_b = addt(n->params, n->param_elems, "bottleneck.bias", {C});
     n->neck_rm = addt(n->buffers, n->buffer_elems, "bottleneck.running_mean", {C});
     n->neck_rv = addt(n->buffers, n->buffer_elems, "bottleneck.running_var", {C});
+    // backward stages = gradient buckets of the data-parallel reducer: up to 4 groups of consecutive blocks, last blocks first
+    n->n_stages = cfg->depth >= 4 ? 4 : cfg->depth;
+    n->stage_first_block.resize(n->n_stages + 1);
+    for (int s = 0; s <= n->n_stages; ++s) n->stage_first_block[s] = cfg->depth - (int)((int64_t)cfg->depth * s / n->n_stages);
 
     VArena a;
     const size_t rows = n->rows, Hd = cfg->mlp_hidden;
@@ -195,15 +204,26 @@ extern "C" int dali_vit_forward(dali_vit* n, void* stream, const float* images, 
     if ((rc = launch_linear_fwd(st, n->patches, n->patch.w, n->P + n->patch.b_off, 0, nullptr, n->pe, nullptr, nullptr, n->B * n->np, n->patch.K, C))) return rc;
     if ((rc = launch_assemble_tokens(st, n->pe, n->P + n->cls_off, n->P + n->pos_off, n->B, n->T, C, n->x0))) return rc;
     const uint16_t* x = n->x0;
-    for (auto& b : n->blocks) {
+    const float* dp = training ? n->dp_scale : nullptr;        // DropPath is the identity in eval mode (vit_pytorch.py:58)
+    n->dp_used = dp;
+    for (int bi = 0; bi < (int)n->blocks.size(); ++bi) {
+        VBlock& b = n->blocks[bi];
         b.x_in = const_cast<uint16_t*>(x);
         if ((rc = launch_layernorm_fwd(st, x, n->P + b.n1.g_off, n->P + b.n1.b_off, rows, C, eps, b.h1, b.n1.mean, b.n1.rstd, nullptr))) return rc;
         if ((rc = launch_linear_fwd(st, b.h1, b.qkv.w, n->P + b.qkv.b_off, 0, nullptr, b.qkv_o, nullptr, nullptr, rows, C, 3 * C))) return rc;
         if ((rc = launch_attention_fwd(st, b.qkv_o, n->B, n->T, n->H, scale, b.att, b.lse))) return rc;
-        if ((rc = launch_linear_fwd(st, b.att, b.proj.w, n->P + b.proj.b_off, 0, x, b.x_mid, nullptr, nullptr, rows, C, C))) return rc;
+        const float* s_att = dp ? dp + (size_t)(2 * bi) * n->B : nullptr;
+        const float* s_mlp = dp ? dp + (size_t)(2 * bi + 1) * n->B : nullptr;
+        if (dp) {          // x_mid = x + s[b] * proj(...): the branch goes to scratch, the scaled add is its own pass
+            if ((rc = launch_linear_fwd(st, b.att, b.proj.w, n->P + b.proj.b_off, 0, nullptr, n->gbuf[1], nullptr, nullptr, rows, C, C))) return rc;
+            if ((rc = launch_rowscale_add(st, n->gbuf[1], s_att, n->B, n->T, C, x, b.x_mid))) return rc;
+        } else if ((rc = launch_linear_fwd(st, b.att, b.proj.w, n->P + b.proj.b_off, 0, x, b.x_mid, nullptr, nullptr, rows, C, C))) return rc;
         if ((rc = launch_layernorm_fwd(st, b.x_mid, n->P + b.n2.g_off, n->P + b.n2.b_off, rows, C, eps, b.h2, b.n2.mean, b.n2.rstd, nullptr))) return rc;
         if ((rc = launch_linear_fwd(st, b.h2, b.fc1.w, n->P + b.fc1.b_off, 1, nullptr, b.act1, b.pre1, nullptr, rows, C, Hd))) return rc;
-        if ((rc = launch_linear_fwd(st, b.act1, b.fc2.w, n->P + b.fc2.b_off, 0, b.x_mid, b.x_out, nullptr, nullptr, rows, Hd, C))) return rc;
+        if (dp) {
+            if ((rc = launch_linear_fwd(st, b.act1, b.fc2.w, n->P + b.fc2.b_off, 0, nullptr, n->gbuf[1], nullptr, nullptr, rows, Hd, C))) return rc;
+            if ((rc = launch_rowscale_add(st, n->gbuf[1], s_mlp, n->B, n->T, C, b.x_mid, b.x_out))) return rc;
+        } else if ((rc = launch_linear_fwd(st, b.act1, b.fc2.w, n->P + b.fc2.b_off, 0, b.x_mid, b.x_out, nullptr, nullptr, rows, Hd, C))) return rc;
         x = b.x_out;
     }
     // final LayerNorm on the cls rows only (x[:, 0], vit_pytorch.py:401-403), then the BN neck (make_models.py:187)
@@ -224,35 +244,74 @@ int lin_bwd(dali_vit* n, hipStream_t st, const Lin& l, const uint16_t* x, const 
 }
 }  // namespace
 
-extern "C" int dali_vit_backward(dali_vit* n, void* stream, const float* d_feat) {
-    DALI_REQUIRE(n && n->P && n->G && d_feat, "dali_vit_backward: null argument or net not bound");
+extern "C" int dali_vit_set_drop_path(dali_vit* n, const float* scales) {
+    DALI_REQUIRE(n, "dali_vit_set_drop_path: null net");
+    n->dp_scale = scales;
+    return DALI_OK;
+}
+
+extern "C" int dali_vit_num_stages(const dali_vit* n) { return n ? n->n_stages : 0; }
+
+// Flat-parameter element range whose gradients are complete once dali_vit_backward_stages has run through `stage`:
+// stage 0 = final norm + fc + neck + the last group of blocks, ..., the last stage also holds cls / pos / patch embedding.
+extern "C" int dali_vit_stage_param_range(const dali_vit* n, int stage, int64_t* begin, int64_t* end) {
+    DALI_REQUIRE(n && begin && end && stage >= 0 && stage < n->n_stages, "dali_vit_stage_param_range: bad argument");
+    const int lo = n->stage_first_block[stage + 1], hi = n->stage_first_block[stage];
+    *begin = (stage == n->n_stages - 1) ? 0 : n->blocks[lo].n1.g_off;
+    *end = (stage == 0) ? n->param_elems : n->blocks[hi].n1.g_off;
+    return DALI_OK;
+}
+
+extern "C" int dali_vit_backward_stages(dali_vit* n, void* stream, const float* d_feat, int stage_begin, int stage_end) {
+    DALI_REQUIRE(n && n->P && n->G, "dali_vit_backward: null argument or net not bound");
     DALI_REQUIRE(n->fwd_training, "dali_vit_backward: the last forward was not in training mode");
+    DALI_REQUIRE(stage_begin >= 0 && stage_end < n->n_stages && stage_begin <= stage_end, "dali_vit_backward: bad stage range %d..%d", stage_begin, stage_end);
     hipStream_t st = (hipStream_t)stream;
     const int C = n->C, rows = n->rows;
+    const float* dp = n->dp_used;
     int rc;
-    // neck + final LayerNorm (cls rows)
-    if ((rc = launch_bn1d_bwd(st, n->gf, d_feat, n->B, C, n->P + n->neck_g, n->neck_mean, n->neck_invstd, n->dgf, n->G + n->neck_g, n->G + n->neck_b))) return rc;
-    if ((rc = launch_layernorm_bwd(st, nullptr, n->cls_rows, n->P + n->fin.g_off, n->fin_mean, n->fin_rstd, nullptr, n->B, C, n->dcls_rows,
-                                   n->G + n->fin.g_off, n->G + n->fin.b_off, n->partial, n->scratch, n->dgf))) return rc;
     uint16_t* dx = n->gbuf[0];
-    DALI_HIP(hipMemsetAsync(dx, 0, (size_t)rows * C * 2, st));
-    DALI_HIP(hipMemcpy2DAsync(dx, (size_t)n->T * C * 2, n->dcls_rows, (size_t)C * 2, (size_t)C * 2, n->B, hipMemcpyDeviceToDevice, st));
-    for (int i = (int)n->blocks.size() - 1; i >= 0; --i) {
-        VBlock& b = n->blocks[i];
-        uint16_t* t1 = n->gbuf[1]; uint16_t* t2 = n->gbuf[2]; uint16_t* t3 = n->gbuf[3];
-        // x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-        if ((rc = lin_bwd(n, st, b.fc2, b.act1, dx, b.pre1, t1, rows))) return rc;                 // t1 = d_pre1 (GELU' fused)
-        if ((rc = lin_bwd(n, st, b.fc1, b.h2, t1, nullptr, t2, rows))) return rc;                  // t2 = d_h2
-        if ((rc = launch_layernorm_bwd(st, t2, b.x_mid, n->P + b.n2.g_off, b.n2.mean, b.n2.rstd, dx, rows, C, t3, n->G + b.n2.g_off,
-                                       n->G + b.n2.b_off, n->partial, n->scratch))) return rc;     // t3 = dx_mid
-        // x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-        if ((rc = lin_bwd(n, st, b.proj, b.att, t3, nullptr, t1, rows))) return rc;                // t1 = d_att
-        if ((rc = launch_attention_bwd(st, b.qkv_o, b.att, t1, b.lse, n->B, n->T, n->H, 0.125f, t2))) return rc;   // t2 = d_qkv
-        if ((rc = lin_bwd(n, st, b.qkv, b.h1, t2, nullptr, t1, rows))) return rc;                  // t1 = d_h1
-        if ((rc = launch_layernorm_bwd(st, t1, b.x_in, n->P + b.n1.g_off, b.n1.mean, b.n1.rstd, t3, rows, C, dx, n->G + b.n1.g_off,
-                                       n->G + b.n1.b_off, n->partial, n->scratch))) return rc;     // dx = dx_in
+    for (int stage = stage_begin; stage <= stage_end; ++stage) {
+        if (stage == 0) {
+            DALI_REQUIRE(d_feat != nullptr, "dali_vit_backward: d_feat is null");
+            // neck (bias frozen, make_models.py:181: no dbeta) + final LayerNorm (cls rows)
+            if ((rc = launch_bn1d_bwd(st, n->gf, d_feat, n->B, C, n->P + n->neck_g, n->neck_mean, n->neck_invstd, n->dgf, n->G + n->neck_g, nullptr))) return rc;
+            if ((rc = launch_layernorm_bwd(st, nullptr, n->cls_rows, n->P + n->fin.g_off, n->fin_mean, n->fin_rstd, nullptr, n->B, C, n->dcls_rows,
+                                           n->G + n->fin.g_off, n->G + n->fin.b_off, n->partial, n->scratch, n->dgf))) return rc;
+            DALI_HIP(hipMemsetAsync(dx, 0, (size_t)rows * C * 2, st));
+            DALI_HIP(hipMemcpy2DAsync(dx, (size_t)n->T * C * 2, n->dcls_rows, (size_t)C * 2, (size_t)C * 2, n->B, hipMemcpyDeviceToDevice, st));
+        }
+        for (int i = n->stage_first_block[stage] - 1; i >= n->stage_first_block[stage + 1]; --i) {
+            VBlock& b = n->blocks[i];
+            uint16_t* t1 = n->gbuf[1]; uint16_t* t2 = n->gbuf[2]; uint16_t* t3 = n->gbuf[3];
+            const float* s_att = dp ? dp + (size_t)(2 * i) * n->B : nullptr;
+            const float* s_mlp = dp ? dp + (size_t)(2 * i + 1) * n->B : nullptr;
+            // x_out = x_mid + s_mlp * fc2(gelu(fc1(LN2(x_mid))))
+            const uint16_t* d_branch = dx;
+            if (dp) { if ((rc = launch_rowscale_add(st, dx, s_mlp, n->B, n->T, C, nullptr, t2))) return rc; d_branch = t2; }
+            if ((rc = lin_bwd(n, st, b.fc2, b.act1, d_branch, b.pre1, t1, rows))) return rc;           // t1 = d_pre1 (GELU' fused)
+            if ((rc = lin_bwd(n, st, b.fc1, b.h2, t1, nullptr, t2, rows))) return rc;                  // t2 = d_h2
+            if ((rc = launch_layernorm_bwd(st, t2, b.x_mid, n->P + b.n2.g_off, b.n2.mean, b.n2.rstd, dx, rows, C, t3, n->G + b.n2.g_off,
+                                           n->G + b.n2.b_off, n->partial, n->scratch))) return rc;     // t3 = dx_mid
+            // x_mid = x_in + s_att * proj(attn(qkv(LN1(x_in))))
+            d_branch = t3;
+            if (dp) { if ((rc = launch_rowscale_add(st, t3, s_att, n->B, n->T, C, nullptr, t2))) return rc; d_branch = t2; }
+            if ((rc = lin_bwd(n, st, b.proj, b.att, d_branch, nullptr, t1, rows))) return rc;          // t1 = d_att
+            if ((rc = launch_attention_bwd(st, b.qkv_o, b.att, t1, b.lse, n->B, n->T, n->H, 0.125f, t2))) return rc;   // t2 = d_qkv
+            if ((rc = lin_bwd(n, st, b.qkv, b.h1, t2, nullptr, t1, rows))) return rc;                  // t1 = d_h1
+            if ((rc = launch_layernorm_bwd(st, t1, b.x_in, n->P + b.n1.g_off, b.n1.mean, b.n1.rstd, t3, rows, C, dx, n->G + b.n1.g_off,
+                                           n->G + b.n1.b_off, n->partial, n->scratch))) return rc;     // dx = dx_in
+        }
+        if (stage == n->n_stages - 1) {
+            // tokens: d pos_embed, d cls_token, d patch embedding
+            if ((rc = launch_assemble_tokens_bwd(st, dx, n->B, n->T, C, n->G + n->pos_off, n->G + n->cls_off, n->gbuf[1]))) return rc;
+            if ((rc = lin_bwd(n, st, n->patch, n->patches, n->gbuf[1], nullptr, nullptr, n->B * n->np))) return rc;
+        }
     }
-    // tokens: d pos_embed, d cls_token, d patch embedding
-    if ((rc = launch_assemble_tokens_bwd(st, dx, n->B, n->T, C, n->G + n->pos_off, n->G + n->cls_off, n->gbuf[1]))) return rc;
-    return lin_bwd(n, st, n->patch, n->patches, n->gbuf[1], nullptr, nullptr, n->B * n->np);
+    return DALI_OK;
+}
+
+extern "C" int dali_vit_backward(dali_vit* n, void* stream, const float* d_feat) {
+    DALI_REQUIRE(n && d_feat, "dali_vit_backward: null argument");
+    return dali_vit_backward_stages(n, stream, d_feat, 0, n->n_stages - 1);
 }

@@ -14,9 +14,26 @@ _MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
 _STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
 
 
+def turb_path(path, turb):
+    """The clean -> turbulence-simulated file pairing of getFeatures.py:24-33 / train_encodersKIT.py:367-377:
+    ``<turb_dir>/<name>_turbstrength<k>.jpg`` (MSMT17: ``<pid>_<name>_turbstrength<k>.jpg``, pid = name up to the first
+    underscore).  ``turb`` = (turbulance_dir_path, strength, dataset)."""
+    import os
+    turb_dir, strength, dataset = turb
+    if strength is None:
+        raise ValueError("turbulance_dir_path is set but turb_strength is None (getFeatures.py:30 formats it with %d)")
+    name = path.split("/")[-1][:-4]
+    if dataset == "MSMT17":
+        name = name.split("_")[0] + "_" + name
+    return os.path.join(turb_dir, name + "_turbstrength%d.jpg" % int(strength))
+
+
 def pil_loader(paths, img_height, img_width, turb=None):
-    """getFeatures.py:18-19 / :31-41: read_image -> Resize((H,W), bicubic) -> ToTensor -> Normalize."""
+    """getFeatures.py:18-19 / :22-41: read_image (the turbulence-simulated file when ``turb`` is given) ->
+    Resize((H,W), bicubic) -> ToTensor -> Normalize."""
     from PIL import Image
+    if turb is not None:
+        paths = [turb_path(p, turb) for p in paths]
     out = np.empty((len(paths), 3, img_height, img_width), dtype=np.float32)
     for i, p in enumerate(paths):
         img = Image.open(p).convert("RGB").resize((img_width, img_height), Image.BICUBIC)

@@ -8,15 +8,70 @@ import torch
 from . import _lib
 
 
+def _param_table(net):
+    """[(name, parameter, flat offset, numel)] of a net on flat storage, by address."""
+    base, out = net.flat_params.data_ptr(), []
+    for name, p in net.named_parameters():
+        out.append((name, p, (p.data_ptr() - base) // 4, p.numel()))
+    return out
+
+
+def active_ranges(net, params=None):
+    """Element ranges of the flat parameter buffer that the optimizer updates, as torch.optim.Adam would: the parameters it
+    was given (``params``; default: those with requires_grad) minus the ones that never receive a gradient (torch skips
+    ``grad is None``: the ViT's unused ``base.fc.*``, make_models.py never calls it; the net lists them in
+    ``_no_grad_params``).  Neighbouring segments are merged across the zero padding between them (padding has p = g = 0,
+    so Adam leaves it at 0)."""
+    table = _param_table(net)
+    no_grad = set(getattr(net, "_no_grad_params", ()))
+    if params is None:
+        chosen = {id(p) for _, p, _, _ in table if p.requires_grad}
+    else:
+        by_ptr = {p.data_ptr(): p for _, p, _, _ in table}
+        chosen = set()
+        for q in params:
+            m = by_ptr.get(q.data_ptr())
+            if m is None:
+                raise _lib.DaliError("FusedAdam: an optimizer parameter is not a view of this net's flat parameter buffer")
+            chosen.add(id(m))
+    segs = sorted((off, off + n, id(p) in chosen and name not in no_grad) for name, p, off, n in table)
+    total = net.flat_params.numel()
+    ranges, cur = [], None
+    for i, (b, e, on) in enumerate(segs):
+        nxt = segs[i + 1][0] if i + 1 < len(segs) else total          # the padding behind a segment belongs to it
+        if on:
+            if cur is not None and cur[1] == b:
+                cur[1] = nxt
+            else:
+                cur = [b, nxt]
+                ranges.append(cur)
+        else:
+            cur = None
+    return [(b, e) for b, e in ranges]
+
+
 class FusedAdam:
-    def __init__(self, net, lr=3.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, torch_optimizer=None):
+    """One fused Adam launch per ACTIVE range of the flat buffers (one range for ResNet-50; two for the ViT, which skips
+    the unused ``base.fc.*`` and the frozen ``bottleneck.bias`` exactly as torch.optim.Adam does for grad-less or
+    excluded parameters)."""
+
+    def __init__(self, net, lr=3.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, torch_optimizer=None, params=None):
         self.net = net
         self.torch_optimizer = torch_optimizer
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.exp_avg = torch.zeros_like(net.flat_params)
         self.exp_avg_sq = torch.zeros_like(net.flat_params)
         self.step_count = 0
-        self.weights_sqsum = torch.zeros(1, device=net.flat_params.device, dtype=torch.float32)
+        self.ranges = active_ranges(net, params)
+        if not self.ranges:
+            raise _lib.DaliError("FusedAdam: no trainable parameter")
+        for b, e in self.ranges:
+            if b % 4 or e % 4:
+                raise _lib.DaliError("FusedAdam: active range [%d, %d) is not 16-byte aligned" % (b, e))
+        dev = net.flat_params.device
+        self._sq = torch.zeros(len(self.ranges), device=dev, dtype=torch.float32)
+        self.weights_sqsum = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._frozen_key, self._frozen_sq = None, None
 
     @classmethod
     def from_torch(cls, optimizer, net):
@@ -25,7 +80,8 @@ class FusedAdam:
         g = optimizer.param_groups[0]
         if g.get("amsgrad", False) or g.get("maximize", False):
             raise _lib.DaliError("amsgrad / maximize are not supported")
-        return cls(net, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"], torch_optimizer=optimizer)
+        return cls(net, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"], torch_optimizer=optimizer,
+                   params=list(g["params"]))
 
     def hyper(self):
         if self.torch_optimizer is not None:
@@ -37,15 +93,38 @@ class FusedAdam:
     def zero_grad(self, set_to_none=True):
         pass                               # the backward overwrites the flat gradient buffer
 
+    def _frozen_sqsum(self):
+        """sum p^2 over the parameters Adam does not touch (the trainer's weights_sum runs over ALL parameters,
+        train_encodersKIT.py:229-231); they only change through load_state_dict / copy_, which bump the version counter."""
+        net = self.net
+        key = net.flat_params._version
+        if self._frozen_key != key or self._frozen_sq is None:
+            tot = torch.zeros(1, device=net.flat_params.device)
+            pos = 0
+            for b, e in self.ranges + [(net.flat_params.numel(), net.flat_params.numel())]:
+                if b > pos:
+                    tot += net.flat_params[pos:b].square().sum()
+                pos = e
+            self._frozen_sq = tot
+        return self._frozen_sq
+
     def step(self, grad_scale=1.0):
         lr, (b1, b2), eps, wd = self.hyper()
         self.step_count += 1
         net = self.net
-        _lib.check(_lib.lib().dali_adam_step(_lib.ctx(net.flat_params.device), _lib.stream_ptr(), _lib.ptr(net.flat_params), _lib.ptr(net.flat_grads),
-                                              _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), net.flat_params.numel(), float(lr), float(b1),
-                                              float(b2), float(eps), float(wd), self.step_count, float(grad_scale), _lib.ptr(self.weights_sqsum)),
-                   "dali_adam_step")
+        L, c, st = _lib.lib(), _lib.ctx(net.flat_params.device), _lib.stream_ptr()
+        frozen = self._frozen_sqsum() if len(self.ranges) > 1 or self.ranges[0] != (0, net.flat_params.numel()) else None
+        for i, (b, e) in enumerate(self.ranges):
+            _lib.check(L.dali_adam_step(c, st, _lib.ptr(net.flat_params[b:e]), _lib.ptr(net.flat_grads[b:e]), _lib.ptr(self.exp_avg[b:e]),
+                                        _lib.ptr(self.exp_avg_sq[b:e]), e - b, float(lr), float(b1), float(b2), float(eps), float(wd),
+                                        self.step_count, float(grad_scale), _lib.ptr(self._sq[i:i + 1])), "dali_adam_step")
+        if frozen is None:
+            self.weights_sqsum = self._sq[0:1]
+        else:
+            self.weights_sqsum = self._sq.sum().reshape(1) + frozen
         net.mark_weights_changed()
+        if frozen is not None:
+            self._frozen_key = net.flat_params._version            # our own bump is not a change of the frozen parameters
 
 
 def ema_update(momentum_net, online_net, beta):

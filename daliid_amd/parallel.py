@@ -43,6 +43,16 @@ def shard_identities(ids, rank, world):
     return ids[rank * per:(rank + 1) * per]
 
 
+def broadcast_from_rank0(obj, group=None):
+    """Rank 0's Python object on every rank (the shuffled identity list and the per-iteration batch order of the PK sampler:
+    every rank must walk the same identities, whatever its own RNG stream did while loading images)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return obj
+    box = [obj if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return box[0]
+
+
 def allreduce_loss_stats(stats, group=None):
     """stats [4] = local (center_num, center_den, proxy_num, proxy_den) -> global sums, in place."""
     if group is not None or (dist.is_initialized() and dist.get_world_size() > 1):

@@ -34,8 +34,18 @@ class SyntheticImages:
         return out
 
     def install(self):
+        """Serve both the evaluation loader (getFeatures.sample) and the training loader (samplePKBatches) from memory:
+        synthetic tensors carry no augmentation, which has to be said explicitly (the default training loader augments)."""
+        from . import train_encodersKIT
         getFeatures.set_image_loader(self.loader)
+        train_encodersKIT.set_train_loader(self.loader)
         return self
+
+    @staticmethod
+    def uninstall():
+        from . import train_encodersKIT
+        getFeatures.set_image_loader(None)
+        train_encodersKIT.set_train_loader(None)
 
     def split(self, n_query_per_id=1):
         """-> (train, gallery, query) record arrays: the last n_query_per_id images of every id are queries."""

@@ -22,13 +22,19 @@ _train_loader = None
 def set_train_loader(fn):
     """fn(paths, img_height, img_width, turb=None) -> float tensor [n,3,H,W]: the loader ``samplePKBatches`` uses, i.e.
     decode + the training transform of train_encodersKIT.py:313-320 (``daliid_amd.transforms.gpu_train_loader`` runs it
-    on the GPU).  None: fall back to the evaluation loader of daliid_amd.getFeatures (resize + normalise, no augmentation)."""
+    on the GPU and is the default).  A loader that does NOT augment must be installed explicitly: falling back to the
+    evaluation transform silently would train a different model than the reference."""
     global _train_loader
     _train_loader = fn
 
 
 def get_train_loader():
-    return _train_loader if _train_loader is not None else get_image_loader()
+    """The installed loader, else ``transforms.gpu_train_loader``: host decode, then Resize / RandomCrop(pad 10) /
+    RandomHorizontalFlip / ColorJitter / RandomErasing / Normalize (train_encodersKIT.py:313-320) on the GPU."""
+    if _train_loader is not None:
+        return _train_loader
+    from .transforms import gpu_train_loader
+    return gpu_train_loader
 
 
 def selectProxiesByTriagulation(X, num_proxies=5):
@@ -150,9 +156,10 @@ class trainer(object):
         fn = ops_eval.l2norm_rows(emb, 1e-9)                                          # :198
         stats, dfn = heads(fn, labels_codes, w)                                       # :200-208 (+ gradient)
         d_emb = ops_eval.l2norm_rows_bwd(emb, dfn, 1e-9)
+        n_stages = net.n_bwd_stages
         if self.process_group is not None and self._dp is None:
-            self._dp = parallel.GradReducer(net.flat_grads, [net._bwd_plan.stage_range(s) for s in range(4)], self.process_group)
-        for stage in range(4):                                                        # :215 backward
+            self._dp = parallel.GradReducer(net.flat_grads, [net._bwd_plan.stage_range(s) for s in range(n_stages)], self.process_group)
+        for stage in range(n_stages):                                                 # :215 backward
             net._backward_stage(d_emb, stage)
             if self._dp is not None:
                 self._dp.reduce_stage(stage)
@@ -172,19 +179,33 @@ class trainer(object):
                                         self.turbulance_dir_path, self.kind_of_transform, K=self.K)
         num_classes = np.unique(selected_labels).shape[0]
         bs = min(self.P, num_classes)
+        # data parallel (one process per GPU, replaces nn.DataParallel's scatter, Encoders.py:39-40): every rank walks rank 0's
+        # identity order and takes its contiguous share of the P identities of each batch (parallel.shard_identities)
+        world = rank = 0
+        if self.process_group is not None:
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+            if bs % world != 0 or bs < 3:
+                raise _lib.DaliError("data parallel: P=%d identities per batch must be >= 3 and divide over %d ranks" % (bs, world))
+            event_dataset.labels_set = parallel.broadcast_from_rank0(event_dataset.labels_set, self.process_group)
         heads = self.build_targets(selected_images, selected_labels)
         self.model_online.train()
         self.model_momentum.eval()
         for inner_iter in np.arange(number_of_iterations):
             print("Iteration number: %d/%d" % (inner_iter + 1, number_of_iterations))
             order = np.random.permutation(len(event_dataset))                         # DataLoader(shuffle=True, drop_last=True)
+            if world:
+                order = parallel.broadcast_from_rank0(order, self.process_group)
             n_batches = len(order) // bs
             acc = torch.zeros(6, device=dev, dtype=torch.float32)
             for b in range(n_batches):
-                parts = [event_dataset[i] for i in order[b * bs:(b + 1) * bs]]
+                ids = order[b * bs:(b + 1) * bs]
+                if world:
+                    ids = parallel.shard_identities(ids, rank, world)
+                parts = [event_dataset[i] for i in ids]
                 batch_imgs = torch.cat([p[0] for p in parts], 0).to(dev, non_blocking=True)
-                if batch_imgs.shape[0] <= 2:                                          # :194-195
-                    continue
+                if not world and batch_imgs.shape[0] <= 2:                            # :194-195 (never under DP: the global batch has
+                    continue                                                          # >= 3 identities, and a skip must be collective)
                 labels_codes = _codes(torch.cat([p[1] for p in parts], 0), dev)
                 w = _sample_weights(torch.from_numpy(np.concatenate([p[2] for p in parts])), current_epoch, self.number_of_epoches, dev)
                 self.train_step(heads, batch_imgs, labels_codes, w, acc)

@@ -177,13 +177,8 @@ def _decode(paths):
 
 
 def _turb_path(path, turb):
-    """the file-name pairing of getFeatures.py:24-33 / train_encodersKIT.py:367-377"""
-    import os
-    turb_dir, strength, dataset = turb
-    name = path.split("/")[-1][:-4]
-    if dataset == "MSMT17":
-        name = name.split("_")[0] + "_" + name
-    return os.path.join(turb_dir, name + "_turbstrength%d.jpg" % strength)
+    from .getFeatures import turb_path
+    return turb_path(path, turb)
 
 
 def gpu_eval_loader(paths, img_height, img_width, turb=None, decode=_decode):

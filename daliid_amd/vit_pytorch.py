@@ -6,8 +6,10 @@ feature so the reference's key names (``cls_token``, ``pos_embed``, ``patch_embe
 ``fc.*``) and call signature ``forward(x, cam_label=None, view_label=None)`` are kept.
 
 Supported (everything the reference's callers use, evaluate.py:179-183): camera = view = 0 (no SIE embedding),
-local_feature = False, drop / attn_drop = 0.  ``drop_path_rate`` must be 0 in training mode (stochastic depth is
-RNG-dependent) -- it is accepted and ignored in eval mode, where DropPath is the identity anyway.
+local_feature = False, drop / attn_drop = 0.  DropPath (vit_pytorch.py:45-62; per-block rate
+``linspace(0, drop_path_rate, depth)``, :338) is applied in training mode: one uniform draw per (branch, sample) on the
+device per step, scale = floor(keep + u) / keep; ``drop_path_uniform`` can be set to inject the draws (parity tests hand
+the same ones to the oracle).  In eval mode it is the identity, as in the reference.
 """
 import ctypes
 import math
@@ -35,8 +37,12 @@ class _VitPlan:
         self.param_elems, self.buffer_elems, self.arena_bytes = pe.value, be.value, ab.value
         self.feat_dim, self.n_params, self.n_buffers = fd.value, np_.value, nb.value
 
+        self.n_stages = int(_lib.lib().dali_vit_num_stages(h))
+
     def stage_range(self, stage):
-        return (0, self.param_elems) if stage == 0 else (0, 0)
+        b, e = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib().dali_vit_stage_param_range(self.h, stage, ctypes.byref(b), ctypes.byref(e)), "dali_vit_stage_param_range")
+        return b.value, e.value
 
     def tensor_table(self, kind):
         out, name = [], ctypes.create_string_buffer(128)
@@ -81,6 +87,8 @@ class ViTNeckNet(nn.Module):
         self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
         self._geom = (patch_size, stride_size, embed_dim, depth, num_heads, int(embed_dim * mlp_ratio), num_classes)
         self.drop_path_rate = float(drop_path_rate)
+        self.drop_path_uniform = None            # optional [2*depth, B] uniform draws in [0,1) used instead of torch.rand (tests)
+        self._dp_scales = None
         self.in_planes = embed_dim
         self._plans, self._arena, self._last_plan, self._refreshed = {}, None, None, (None, -1)
         probe = self._plan(1)
@@ -102,6 +110,9 @@ class ViTNeckNet(nn.Module):
             if attr == "running_var":
                 leaf.register_buffer("num_batches_tracked", self.flat_nbt[0])
         self.bottleneck.bias.requires_grad_(False)                                   # make_models.py:181
+        # base.fc is built but never called (vit_pytorch.py:405-408 returns the cls feature): its grad stays None in the
+        # reference, so torch.optim.Adam skips it (no weight decay either)
+        self._no_grad_params = ("base.fc.weight", "base.fc.bias")
         self.reset_parameters(seed)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_weights_changed())
 
@@ -171,11 +182,11 @@ class ViTNeckNet(nn.Module):
     def _run_forward(self, x, training, want_global=False):
         if x.dim() != 4 or tuple(x.shape[1:]) != (3,) + self.img_size:
             raise _lib.DaliError("Input image size (%s) doesn't match model (%s)" % (tuple(x.shape[2:]), self.img_size))   # vit_pytorch.py:282-284
-        if training and self.drop_path_rate > 0:
-            raise _lib.DaliError("drop_path_rate > 0 is not supported in training mode (stochastic depth is RNG-dependent); build with drop_path_rate=0")
         x = x.to(device=self._device, dtype=torch.float32).contiguous()
         plan = self._plan(x.shape[0])
         self._activate(plan)
+        self._dp_scales = self._draw_drop_path(x.shape[0]) if training else None
+        _lib.check(_lib.lib().dali_vit_set_drop_path(plan.h, _lib.ptr(self._dp_scales)), "dali_vit_set_drop_path")
         feat = torch.empty(x.shape[0], plan.feat_dim, device=self._device)
         gf = torch.empty_like(feat) if want_global else None
         _lib.check(_lib.lib().dali_vit_forward(plan.h, _lib.stream_ptr(), _lib.ptr(x), int(training), _lib.ptr(feat), _lib.ptr(gf)), "dali_vit_forward")
@@ -184,16 +195,36 @@ class ViTNeckNet(nn.Module):
             self._bwd_plan = plan
         return (feat, gf) if want_global else feat
 
-    # the trainer / data-parallel reducer drive the backward per "stage"; the ViT plan has a single stage
-    def _backward_stage(self, d_feat, stage):
-        if stage == 0:
-            self._run_backward(d_feat, attach=False)
+    def _draw_drop_path(self, batch):
+        """vit_pytorch.py:45-62 for every residual branch of every block at once: fp32 [2*depth, batch] of floor(keep + u)/keep,
+        keep = 1 - linspace(0, rate, depth)[block]; blocks whose rate is 0 are nn.Identity in the reference (:171)."""
+        if self.drop_path_rate <= 0:
+            return None
+        depth = self._geom[3]
+        dpr = torch.linspace(0, self.drop_path_rate, depth).repeat_interleave(2).to(self._device).unsqueeze(1)      # :338
+        u = self.drop_path_uniform
+        if u is None:
+            u = torch.rand(2 * depth, batch, device=self._device)
+        elif tuple(u.shape) != (2 * depth, batch):
+            raise _lib.DaliError("drop_path_uniform must be [2*depth, batch] = %s" % ((2 * depth, batch),))
+        keep = 1.0 - dpr
+        return ((keep + u.to(self._device, torch.float32)).floor() / keep).contiguous()
 
-    def _run_backward(self, d_feat, attach=True):
+    # the trainer / data-parallel reducer drive the backward per stage (= gradient bucket): groups of blocks, last group first
+    @property
+    def n_bwd_stages(self):
+        return self._bwd_plan.n_stages
+
+    def _backward_stage(self, d_feat, stage):
         plan = self._bwd_plan
         if plan is not self._last_plan:
             raise _lib.DaliError("backward() after another forward of a different shape is not supported")
-        _lib.check(_lib.lib().dali_vit_backward(plan.h, _lib.stream_ptr(), _lib.ptr(d_feat, torch.float32, "d_feat")), "dali_vit_backward")
+        _lib.check(_lib.lib().dali_vit_backward_stages(plan.h, _lib.stream_ptr(), _lib.ptr(d_feat, torch.float32, "d_feat"), stage, stage),
+                   "dali_vit_backward_stages")
+
+    def _run_backward(self, d_feat, attach=True):
+        for stage in range(self.n_bwd_stages):
+            self._backward_stage(d_feat, stage)
         if attach:
             for name, p in zip(self._param_names, self.parameters()):
                 p.grad = self._grad_views[name] if p.requires_grad else None

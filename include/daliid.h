@@ -354,6 +354,16 @@ int dali_vit_bind(dali_vit* net, float* params, float* grads, float* buffers, vo
 int dali_vit_refresh_weights(dali_vit* net, void* stream);
 int dali_vit_forward(dali_vit* net, void* stream, const float* images, int training, float* feat, float* global_feat);
 int dali_vit_backward(dali_vit* net, void* stream, const float* d_feat);
+/* Backward in stages = gradient buckets of the data-parallel reducer (daliid_amd/parallel.py): stage 0 = neck + final norm + the
+ * last group of blocks (consumes d_feat), ..., the last stage also holds cls / pos / patch embedding.  Replaces the autograd
+ * graph nn.DataParallel reduces as a whole (Encoders.py:39-40). */
+int dali_vit_num_stages(const dali_vit* net);
+int dali_vit_stage_param_range(const dali_vit* net, int stage, int64_t* begin, int64_t* end);
+int dali_vit_backward_stages(dali_vit* net, void* stream, const float* d_feat, int stage_begin, int stage_end);
+/* DropPath (vit_pytorch.py:45-62; per block rate linspace(0, drop_path_rate, depth), :338): scales = device fp32 [2*depth][batch],
+ * row 2i = attention branch of block i, row 2i+1 = its MLP branch, each entry floor(keep + u)/keep in {0, 1/keep}.  Applied by
+ * training-mode forwards (and mirrored by the backward) until reset with NULL; the buffer must outlive the backward. */
+int dali_vit_set_drop_path(dali_vit* net, const float* scales);
 
 #ifdef __cplusplus
 }

@@ -75,7 +75,10 @@ def _worker(rank, world, port, out_dir):
     for stage in range(4):
         red.reduce_stage(stage)
     red.finish()
-    torch.save({"stats": stats, "grads": flat}, os.path.join(out_dir, "rank%d.pt" % rank))
+    # the PK sampler's identity order is rank 0's on every rank, whatever the local RNG stream did (trainer.train under DP)
+    order = parallel.broadcast_from_rank0(np.random.RandomState(100 + rank).permutation(16))
+    torch.save({"stats": stats, "grads": flat, "order": order, "mine": parallel.shard_identities(order[:4], rank, world)},
+               os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,7 +87,10 @@ def test_two_rank_step_equals_sharded_oracle(tmp_path):
     world = 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    outs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    outs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    want = np.random.RandomState(100).permutation(16)
+    for r, o in enumerate(outs):
+        assert np.array_equal(o["order"], want) and np.array_equal(o["mine"], want[2 * r:2 * r + 2])
     # single-process reference: shards run one after the other with shared weights; normalisers summed first
     from daliid_amd import parallel
     model, ids, K, imgs, labels, distortion, centers, clabels, proxies, plabels = _problem()

@@ -108,4 +108,4 @@ def test_fusion_mirror_end_to_end(mods):
             assert abs(mAP - map_ref) < 2e-3, (name, mAP, map_ref)
             np.testing.assert_allclose(cmc[:5], cmc_ref[:5], atol=0.05)
     finally:
-        getFeatures.set_image_loader(None)
+        synthetic.SyntheticImages.uninstall()

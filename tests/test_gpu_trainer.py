@@ -18,7 +18,7 @@ def env():
     from daliid_amd import Encoders, synthetic, train_encodersKIT, validateModels, getFeatures
     data = synthetic.SyntheticImages(n_ids=8, per_id=6, n_cams=3, seed=5, noise=0.4).install()
     yield Encoders, data, train_encodersKIT, validateModels, getFeatures
-    getFeatures.set_image_loader(None)
+    synthetic.SyntheticImages.uninstall()
 
 
 def _models(Encoders, seed=7):
