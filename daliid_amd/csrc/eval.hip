@@ -324,13 +324,19 @@ __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __re
 // market1501 ranking without a row sort.  One 256-thread block per query.
 //   kept(g)  = !(g_pid == q_pid && g_cam == q_cam)                  (junk removal)
 //   match(g) = kept(g) && g_pid == q_pid
+// The gallery is indexed by identity ONCE per evaluation (rank_index_*: counting sort of the gallery positions by pid, on
+// the device), so a query finds its same-identity entries -- matches and junk -- as one slice of that index instead of
+// scanning all ng ids (10k x 100k: 4 GB of id reads gone; only the distance row is read, 4 bytes per pair).
 // Sort the matches by key (dist, index) in LDS (bitonic).  Every kept gallery entry is binned by the
 // number of matches with a smaller key (binary search); with c[b] the bin counts,
 //   position (1-based, among kept) of the j-th match = c[0] + ... + c[j]
 //   AP = mean_j (j+1) / position_j ,  first-hit rank = c[0] - 1.
-// Reads the distmat row once (coalesced): HBM-bound, 4 bytes per pair.
+// LDS is sized in two tiers (the row scan is HBM-bound and needs many workgroups per CU in flight): RANK_PSMALL same-identity
+// entries per query in the first launch (16 KiB of LDS: 8+ workgroups per CU); queries with more are flagged and redone by a
+// second launch with room for RANK_PMAX; beyond that DALI_ERR_LIMIT through status[0].
 // ------------------------------------------------------------------------------------------------
-constexpr int RANK_PMAX = 4096;
+constexpr int RANK_PSMALL = 512, RANK_PMAX = 4096;
+constexpr int RANK_MAX_PID_RANGE = 1 << 20;      // identity codes must span at most this range (the mirrors pass dense codes): status 2 otherwise
 
 __device__ __forceinline__ bool key_less(float da, int ia, float db, int ib) {
     return da < db || (da == db && ia < ib);
@@ -343,37 +349,94 @@ __device__ __forceinline__ unsigned long long rank_key(float d, int g) {
     return ((unsigned long long)b << 32) | (unsigned int)g;
 }
 
+// ---- gallery index by identity: info = {min pid, max pid}; counts/starts over [min, max]; order = gallery positions grouped by pid ----
+__global__ __launch_bounds__(256) void rank_index_minmax_kernel(const int32_t* __restrict__ g_pids, int ng, int32_t* __restrict__ info) {
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) { const int p = g_pids[g]; lo = min(lo, p); hi = max(hi, p); }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&info[0], lo); atomicMax(&info[1], hi); }
+}
+__global__ __launch_bounds__(256) void rank_index_count_kernel(const int32_t* __restrict__ g_pids, int ng, const int32_t* __restrict__ info,
+                                                                int32_t* __restrict__ counts, int32_t* __restrict__ status) {
+    const int lo = info[0];
+    const long long range = (long long)info[1] - lo + 1;
+    if (range > RANK_MAX_PID_RANGE) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(status, 2); return; }
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) atomicAdd(&counts[g_pids[g] - lo], 1);
+}
+// one block: starts[r] = exclusive prefix of counts (range + 1 entries), cursors zeroed
+__global__ __launch_bounds__(1024) void rank_index_scan_kernel(const int32_t* __restrict__ info, const int32_t* __restrict__ counts,
+                                                               int32_t* __restrict__ starts, int32_t* __restrict__ cursor) {
+    __shared__ int s_part[1024];
+    const long long range64 = (long long)info[1] - info[0] + 1;
+    if (range64 > RANK_MAX_PID_RANGE) return;
+    const int range = (int)range64, tid = threadIdx.x;
+    const int per = (range + 1023) / 1024, b = tid * per, e = min(b + per, range);
+    int sum = 0;
+    for (int r = b; r < e; ++r) sum += counts[r];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int add = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += add;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int r = b; r < e; ++r) { starts[r] = run; cursor[r] = 0; run += counts[r]; }
+    if (tid == 1023) starts[range] = s_part[1023];
+}
+__global__ __launch_bounds__(256) void rank_index_scatter_kernel(const int32_t* __restrict__ g_pids, int ng, const int32_t* __restrict__ info,
+                                                                  const int32_t* __restrict__ starts, int32_t* __restrict__ cursor,
+                                                                  int32_t* __restrict__ order) {
+    const int lo = info[0];
+    if ((long long)info[1] - lo + 1 > RANK_MAX_PID_RANGE) return;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        const int r = g_pids[g] - lo;
+        order[starts[r] + atomicAdd(&cursor[r], 1)] = g;          // order inside an identity is irrelevant: matches are sorted by key below
+    }
+}
+
+// PASS 0: every query, LDS for PCAP = RANK_PSMALL; larger identities set pending[q].  PASS 1: only the pending queries, PCAP = RANK_PMAX.
+template <int PCAP, int PASS>
 __global__ __launch_bounds__(256) void rank_query_kernel(const float* __restrict__ distmat, const int32_t* __restrict__ q_pids,
-                                                          const int32_t* __restrict__ g_pids, const int32_t* __restrict__ q_cams,
-                                                          const int32_t* __restrict__ g_cams, int nq, int ng,
+                                                          const int32_t* __restrict__ q_cams, const int32_t* __restrict__ g_cams,
+                                                          const int32_t* __restrict__ info, const int32_t* __restrict__ starts,
+                                                          const int32_t* __restrict__ order, int nq, int ng,
                                                           float* __restrict__ ap_out, int32_t* __restrict__ first_rank,
-                                                          int32_t* __restrict__ status) {
-    __shared__ unsigned long long s_key[RANK_PMAX];    // (orderable distance bits << 32) | gallery index: one 8-byte LDS read per compare
-    __shared__ int s_cnt[RANK_PMAX + 1];
-    __shared__ int s_junk[RANK_PMAX];
+                                                          int32_t* __restrict__ pending, int32_t* __restrict__ status) {
+    __shared__ unsigned long long s_key[PCAP];    // (orderable distance bits << 32) | gallery index: one 8-byte LDS read per compare
+    __shared__ int s_cnt[PCAP + 1];
+    __shared__ int s_junk[PCAP];
     __shared__ int s_n, s_nj;
     __shared__ float s_red[4];
     __shared__ int s_scan[256];
     const int q = blockIdx.x, tid = threadIdx.x;
+    if (PASS == 1 && pending[q] == 0) return;
     const float* drow = distmat + (size_t)q * ng;
     const int qp = q_pids[q], qc = q_cams[q];
-    if (tid == 0) { s_n = 0; s_nj = 0; }
+    // 1. this query's identity slice of the gallery index: matches (other camera) and junk (same camera)
+    const int lo = info[0], hi = info[1];
+    if ((long long)hi - lo + 1 > RANK_MAX_PID_RANGE) { if (tid == 0) { ap_out[q] = 0.f; first_rank[q] = -1; } return; }     // status 2 set by the index build
+    int sb = 0, se = 0;
+    if (qp >= lo && qp <= hi) { sb = starts[qp - lo]; se = starts[qp - lo + 1]; }
+    const int nsame = se - sb;
+    if (nsame == 0) {
+        if (tid == 0) { ap_out[q] = 0.f; first_rank[q] = -1; if (PASS == 0) pending[q] = 0; }
+        return;
+    }
+    if (nsame > PCAP) {
+        if (tid == 0) {
+            ap_out[q] = 0.f; first_rank[q] = -1;
+            if (PASS == 0) pending[q] = 1; else atomicMax(status, 1);
+        }
+        return;
+    }
+    if (tid == 0) { s_n = 0; s_nj = 0; if (PASS == 0) pending[q] = 0; }
     __syncthreads();
-    // 1. collect matches (same pid, other camera) and junk (same pid, same camera); ids are L2-resident
-    const bool vec = (ng & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_pids) | reinterpret_cast<uintptr_t>(drow)) & 15) == 0;
-    auto visit_pid = [&](int g, int pid) {
-        if (pid == qp) {
-            if (g_cams[g] != qc) { const int slot = atomicAdd(&s_n, 1); if (slot < RANK_PMAX) s_key[slot] = rank_key(drow[g], g); }
-            else { const int slot = atomicAdd(&s_nj, 1); if (slot < RANK_PMAX) s_junk[slot] = g; }
-        }
-    };
-    if (vec) {
-        for (int g = tid * 4; g < ng; g += 1024) {
-            const int4 p = *reinterpret_cast<const int4*>(g_pids + g);
-            visit_pid(g, p.x); visit_pid(g + 1, p.y); visit_pid(g + 2, p.z); visit_pid(g + 3, p.w);
-        }
-    } else {
-        for (int g = tid; g < ng; g += 256) visit_pid(g, g_pids[g]);
+    for (int t = tid; t < nsame; t += 256) {
+        const int g = order[sb + t];
+        if (g_cams[g] != qc) s_key[atomicAdd(&s_n, 1)] = rank_key(drow[g], g);
+        else s_junk[atomicAdd(&s_nj, 1)] = g;
     }
     __syncthreads();
     const int np = s_n, nj = s_nj;
@@ -381,10 +444,7 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* __restrict
         if (tid == 0) { ap_out[q] = 0.f; first_rank[q] = -1; }
         return;
     }
-    if (np > RANK_PMAX || nj > RANK_PMAX) {
-        if (tid == 0) { atomicMax(status, 1); ap_out[q] = 0.f; first_rank[q] = -1; }
-        return;
-    }
+    const bool vec = (ng & 3) == 0 && (reinterpret_cast<uintptr_t>(drow) & 15) == 0;
     int npad = 1;
     while (npad < np) npad <<= 1;
     for (int t = np + tid; t < npad; t += 256) s_key[t] = ~0ull;                  // above every real key
@@ -668,16 +728,41 @@ extern "C" int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat,
     hipStream_t st = (hipStream_t)stream;
     float* ap_buf = ap;
     int32_t* fr_buf = first_rank;
-    if (!ap_buf || !fr_buf) {
-        char* ws = static_cast<char*>(workspace(ctx, align_up((size_t)nq * 4, 256) * 2));
-        if (!ws) return DALI_ERR_NOMEM;
-        if (!ap_buf) ap_buf = reinterpret_cast<float*>(ws);
-        if (!fr_buf) fr_buf = reinterpret_cast<int32_t*>(ws + align_up((size_t)nq * 4, 256));
-    }
+    // gallery index by identity (counting sort over [min pid, max pid]) in the context workspace, behind the ap / first_rank scratch
     DALI_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(rank_query_kernel, dim3(nq), dim3(256), 0, st, distmat, q_pids, g_pids, q_camids, g_camids, nq, ng,
-                       ap_buf, fr_buf, status);
-    DALI_LAUNCH_CHECK();
+    {
+        const size_t head = (!ap || !first_rank) ? align_up((size_t)nq * 4, 256) * 2 : 0;
+        const size_t b_info = 256, b_order = align_up((size_t)ng * 4, 256), b_pend = align_up((size_t)nq * 4, 256);
+        const size_t b_tab = align_up(((size_t)RANK_MAX_PID_RANGE + 1) * 4, 256);
+        char* ws = static_cast<char*>(workspace(ctx, head + b_info + b_order + b_pend + 3 * b_tab));
+        if (!ws) return DALI_ERR_NOMEM;
+        if (!ap) ap_buf = reinterpret_cast<float*>(ws);
+        if (!first_rank) fr_buf = reinterpret_cast<int32_t*>(ws + align_up((size_t)nq * 4, 256));
+        int32_t* info = reinterpret_cast<int32_t*>(ws + head);
+        int32_t* order = reinterpret_cast<int32_t*>(ws + head + b_info);
+        int32_t* pending = reinterpret_cast<int32_t*>(ws + head + b_info + b_order);
+        int32_t* counts = reinterpret_cast<int32_t*>(ws + head + b_info + b_order + b_pend);
+        int32_t* starts = counts + b_tab / 4;
+        int32_t* cursor = starts + b_tab / 4;
+        const int32_t init[2] = {0x7fffffff, (int32_t)0x80000000};
+        DALI_HIP(hipMemcpyAsync(info, init, sizeof(init), hipMemcpyHostToDevice, st));
+        const int gb = (ng + 255) / 256 < 1024 ? (ng + 255) / 256 : 1024;
+        hipLaunchKernelGGL(rank_index_minmax_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info);
+        DALI_LAUNCH_CHECK();
+        DALI_HIP(hipMemsetAsync(counts, 0, ((size_t)RANK_MAX_PID_RANGE + 1) * 4, st));
+        hipLaunchKernelGGL(rank_index_count_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info, counts, status);
+        DALI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rank_index_scan_kernel, dim3(1), dim3(1024), 0, st, info, counts, starts, cursor);
+        DALI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rank_index_scatter_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info, starts, cursor, order);
+        DALI_LAUNCH_CHECK();
+        hipLaunchKernelGGL((rank_query_kernel<RANK_PSMALL, 0>), dim3(nq), dim3(256), 0, st, distmat, q_pids, q_camids, g_camids, info, starts, order,
+                           nq, ng, ap_buf, fr_buf, pending, status);
+        DALI_LAUNCH_CHECK();
+        hipLaunchKernelGGL((rank_query_kernel<RANK_PMAX, 1>), dim3(nq), dim3(256), 0, st, distmat, q_pids, q_camids, g_camids, info, starts, order,
+                           nq, ng, ap_buf, fr_buf, pending, status);
+        DALI_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(rank_reduce_kernel, dim3(1), dim3(256), 0, st, ap_buf, fr_buf, nq, max_rank, cmc, mAP, map64, num_valid);
     DALI_LAUNCH_CHECK();
     return DALI_OK;

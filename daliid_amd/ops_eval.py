@@ -107,8 +107,10 @@ def rank_eval(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, return_p
     qc, gc = factorize_ids(q_camids, g_camids)
     t = lambda a: torch.from_numpy(a).to(dev)
     o = rank_eval_codes(distmat, t(qp), t(gp), t(qc), t(gc), max_rank)
-    if int(o["status"].item()) != 0:
-        raise _lib.DaliError("dali_rank_eval: a query has more than 4096 matches or junk entries (documented limit)")
+    st = int(o["status"].item())
+    if st != 0:
+        raise _lib.DaliError("dali_rank_eval: " + ("a query's identity has more than 4096 gallery entries (documented limit)" if st == 1 else
+                                                   "identity codes span more than 2^20 values (documented limit)"))
     if int(o["nvalid"].item()) == 0:
         raise AssertionError("Error: all query identities do not appear in gallery")
     res = (o["cmc"].cpu().numpy(), float(o["map64"].item()))

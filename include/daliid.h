@@ -100,7 +100,9 @@ int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, const float
  * Outputs (device): cmc[max_rank] fp32, mAP[1] fp32 (+ fp64 copy in map64[1], nullable),
  * num_valid[1] int32 (queries with at least one match after junk removal),
  * per-query ap[nq] fp32 and first_rank[nq] int32 (-1 = invalid query) -- both nullable.
- * Limit: at most 4096 matches per query (DALI_ERR_LIMIT is reported through status[0]). */
+ * The gallery is indexed by identity on the device first (counting sort), so the ids are read once per evaluation, not once per
+ * query.  Limits, reported through status[0] (device): 1 = a query's identity has more than 4096 gallery entries; 2 = the gallery
+ * identity codes span more than 2^20 values (pass dense codes, as the mirror's factorize_ids does). */
 int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat, const int32_t* q_pids,
                    const int32_t* g_pids, const int32_t* q_camids, const int32_t* g_camids, int nq, int ng,
                    int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid,

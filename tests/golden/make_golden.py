@@ -362,8 +362,56 @@ def gen_vit():
     print("vit.npz ok: tiny y", tuple(y.shape), "full y", tuple(yf.shape), "keys", len(keys))
 
 
+def gen_vit_droppath():
+    """DropPath in training mode (vit_pytorch.py:45-62, wired :178-179 with the per-block rates of :338): the reference's
+    TransReID, tiny config, rate 0.5 over depth 3 (block rates 0, 0.25, 0.5), forward + backward under a fixed CPU seed.
+    The uniform draws the forward consumed are replayed from the same seed (one torch.rand((B,1,1)) per DropPath module in
+    execution order; block 0 is nn.Identity) and stored, so that the oracle / the HIP plan can be fed the same draws."""
+    import vit_pytorch as V
+    out = {}
+    depth, rate, B = 3, 0.5, 6
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(5)
+        tiny = V.TransReID(img_size=(32, 32), patch_size=8, stride_size=8, embed_dim=64, depth=depth, num_heads=1,
+                           mlp_ratio=4, qkv_bias=True, drop_path_rate=rate, num_classes=10,
+                           norm_layer=__import__("functools").partial(torch.nn.LayerNorm, eps=1e-6))
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for p in tiny.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    w = torch.randn(B, 64, generator=g)
+    tiny.train()
+    torch.manual_seed(77)
+    y = tiny(x)
+    (y * w).sum().backward()
+    torch.manual_seed(77)                                 # replay the draws of the forward above
+    u = torch.full((2 * depth, B), 0.5)
+    for i in range(depth):
+        if isinstance(tiny.blocks[i].drop_path, torch.nn.Identity):
+            continue
+        for br in range(2):
+            u[2 * i + br] = torch.rand((B, 1, 1)).reshape(B)
+    # sanity: some sample must actually be dropped somewhere, some kept
+    dpr = torch.linspace(0, rate, depth).repeat_interleave(2).unsqueeze(1)
+    kept = (1 - dpr + u).floor()
+    assert 0 < int((kept == 0).sum()) < kept.numel(), kept
+    for k, v in tiny.state_dict().items():
+        out["sd/" + k] = v.numpy()
+    out["x"] = x.numpy(); out["w"] = w.numpy(); out["y"] = y.detach().numpy(); out["u"] = u.numpy()
+    out["rate"] = np.float64(rate); out["depth"] = np.int64(depth)
+    for k, p in tiny.named_parameters():
+        if p.grad is not None:
+            out["grad/" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "vit_droppath.npz"), **out)
+    print("vit_droppath.npz ok: y", tuple(y.shape), "dropped", int((kept == 0).sum()), "of", kept.numel())
+
+
 def main():
     install_shims()
+    if sys.argv[1:] == ["--only", "vit_droppath"]:                       # added in round 2
+        gen_vit_droppath()
+        return
     import losses as ref_losses
     if sys.argv[1:] == ["--only", "triplet"]:                            # added after the first fixtures were frozen
         gen_triplet(ref_losses)
@@ -374,6 +422,7 @@ def main():
     gen_proxies(T)
     gen_trainer(T)
     gen_vit()
+    gen_vit_droppath()
 
 
 if __name__ == "__main__":

@@ -124,3 +124,59 @@ def test_two_rank_train_steps_match_sharded_emulation(tmp_path):
     np.testing.assert_allclose(outs[0]["grads"].numpy(), gsum.cpu().numpy(), rtol=2e-3, atol=2e-5 * float(gsum.abs().max()))
     d = (outs[0]["params"] - net.flat_params.cpu()).abs().max().item()
     assert d < 2e-4, d            # Adam turns rounding-level gradient differences into <= lr-sized parameter differences
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """backend "nccl" (= RCCL): one rank per GPU.  A one-GPU box can only host world size 1, which still runs every RCCL call
+    of the step (communicator init, the 4-float loss-statistics all-reduce, the per-stage gradient all-reduces on the side
+    stream with async work handles)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from daliid_amd.losses import _codes
+    from daliid_amd.train_encodersKIT import trainer
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+    dev, online, momentum, centers, proxies, NC, imgs, ids, labels, dist_lv, sample_w, LossHeads = _setup()
+    pg = dist.group.WORLD
+    opt = torch.optim.Adam(online.parameters(), lr=3.5e-4, weight_decay=5e-4)
+    tr = trainer("Synthetic", None, "resnet50", {}, 64, 32, None, False, 0, opt, 4, 4, 0.05, 0.9, 0.4, 250, online, momentum, [rank], "t", process_group=pg)
+    heads = LossHeads(centers, np.arange(NC), proxies, np.repeat(np.arange(NC), 3), 0.05, 0.4, pg)
+    online.train()
+    acc = torch.zeros(6, device=dev)
+    for step in range(2):
+        stats = tr.train_step(heads, imgs.to(dev), _codes(labels, dev), sample_w(dist_lv, 10, 250, dev), acc)
+    torch.cuda.synchronize()
+    assert tr._dp is not None and dist.get_backend() == "nccl"
+    torch.save({"params": online.module.flat_params.cpu(), "stats": stats.cpu(), "grads": online.module.flat_grads.cpu()},
+               os.path.join(out_dir, "rccl_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_step_and_changes_nothing_at_world_size_1(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = min(torch.cuda.device_count(), 2)
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "rccl_rank%d.pt" % r)) for r in range(world)]
+    for o in outs:
+        assert torch.isfinite(o["params"]).all() and torch.isfinite(o["grads"]).all()
+    if world == 1:
+        # a 1-rank all-reduce is the identity: same two steps without a process group give the same bits
+        from daliid_amd.losses import _codes
+        from daliid_amd.train_encodersKIT import trainer
+        dev, online, momentum, centers, proxies, NC, imgs, ids, labels, dist_lv, sample_w, LossHeads = _setup()
+        opt = torch.optim.Adam(online.parameters(), lr=3.5e-4, weight_decay=5e-4)
+        tr = trainer("Synthetic", None, "resnet50", {}, 64, 32, None, False, 0, opt, 4, 4, 0.05, 0.9, 0.4, 250, online, momentum, [0], "t")
+        heads = LossHeads(centers, np.arange(NC), proxies, np.repeat(np.arange(NC), 3), 0.05, 0.4, None)
+        online.train()
+        acc = torch.zeros(6, device=dev)
+        for step in range(2):
+            stats = tr.train_step(heads, imgs.to(dev), _codes(labels, dev), sample_w(dist_lv, 10, 250, dev), acc)
+        assert torch.equal(outs[0]["params"], online.module.flat_params.cpu())
+        assert torch.equal(outs[0]["grads"], online.module.flat_grads.cpu())
+    else:
+        for k in ("params", "grads", "stats"):
+            assert torch.equal(outs[0][k], outs[1][k]), k

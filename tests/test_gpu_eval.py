@@ -151,3 +151,65 @@ def test_config5_full_size_properties(ops):
     assert (out[:300, 5000:5600] - a).abs().max().item() == 0.0           # tile position does not change values
     del out
     torch.cuda.empty_cache()
+
+
+def test_rank_eval_large_identities_second_tier_and_limit(ops):
+    """The ranking kernel keeps a query's same-identity gallery entries in LDS: up to 512 in the first launch, up to 4096 in the
+    second; beyond that the documented limit is an error, not a wrong number."""
+    from daliid_amd._lib import DaliError
+    rng = np.random.default_rng(3)
+    ng, nq = 6000, 12
+    gp = np.concatenate((np.zeros(700, np.int64), np.ones(3000, np.int64), rng.integers(2, 40, ng - 3700)))   # identity 0: 700 entries, identity 1: 3000
+    rng.shuffle(gp)
+    gc = rng.integers(0, 3, ng)
+    qp = np.array([0, 1, 0, 1, 5, 7, 9, 1, 0, 38, 39, 1000])                                # the last query's identity is not in the gallery
+    qc = rng.integers(0, 3, nq)
+    dist = rng.random((nq, ng)).astype(np.float32)
+    ref_cmc, ref_map = E.eval_market1501(dist, qp, gp, qc, gc, max_rank=50)
+    cmc, mAP = ops.rank_eval(torch.from_numpy(dist).cuda(), qp, gp, qc, gc, max_rank=50)
+    np.testing.assert_allclose(cmc, ref_cmc, atol=1e-6)
+    assert abs(mAP - ref_map) < 1e-6
+    gp2 = np.zeros(5000, np.int64)
+    with pytest.raises(DaliError, match="4096"):
+        ops.rank_eval(torch.from_numpy(dist[:, :5000].copy()).cuda(), qp, gp2, qc, gc[:5000])
+    # sparse identity codes straight through the code-level entry: refused with status 2, never mis-indexed
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).cuda()
+    wide = gp.copy(); wide[0] = 1 << 29
+    o = ops.rank_eval_codes(torch.from_numpy(dist).cuda(), t(qp), t(wide), t(qc), t(gc))
+    assert int(o["status"].item()) == 2
+
+
+def test_config5_rank_eval_full_size_properties(ops):
+    """configs[4], CMC/mAP leg at 10k x 100k (1000 identities x 100 gallery entries, 10 queries per identity): per-query AP and
+    first-hit rank of 64 sampled queries against a brute-force argsort of their rows; the aggregate against the per-query values;
+    perfectly separated identities -> mAP = 1, rank-1 = 1."""
+    nq, ng, n_ids = 10000, 100000, 1000
+    rng = np.random.default_rng(12)
+    g_pids = np.repeat(np.arange(n_ids), 100); q_pids = np.repeat(np.arange(n_ids), 10)
+    g_cams = rng.integers(0, 6, ng); q_cams = rng.integers(0, 6, nq)
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    dist = torch.rand(nq, ng, device="cuda", generator=gen)
+    cmc, mAP, ap, first = ops.rank_eval(dist, q_pids, g_pids, q_cams, g_cams, max_rank=50, return_per_query=True)
+    valid = first >= 0
+    assert valid.sum() == nq                                        # 100 entries over 6 cameras: every query keeps a match
+    assert abs(mAP - float(ap[valid].astype(np.float64).mean())) < 1e-6
+    hist = np.bincount(first[valid], minlength=ng)[:50].cumsum() / valid.sum()
+    np.testing.assert_allclose(cmc, hist, atol=1e-6)
+    sample = rng.choice(nq, 64, replace=False)
+    rows = dist[torch.from_numpy(sample).cuda()].cpu().numpy()
+    for r, q in zip(rows, sample):
+        order = np.lexsort((np.arange(ng), r))                       # (distance, index): the kernel's tie order
+        keep = ~((g_pids[order] == q_pids[q]) & (g_cams[order] == q_cams[q]))
+        m = (g_pids[order] == q_pids[q])[keep]
+        pos = np.flatnonzero(m)
+        ref_ap = float(np.mean((np.arange(len(pos)) + 1) / (pos + 1)))
+        assert first[q] == pos[0] and abs(ap[q] - ref_ap) < 1e-6, (q, first[q], pos[0], ap[q], ref_ap)
+    # separated identities: same-identity pairs closest
+    same = torch.from_numpy(q_pids).cuda()[:, None] == torch.from_numpy(g_pids).cuda()[None, :]
+    dist.mul_(0.5).add_(0.5)
+    dist[same] -= 0.5
+    del same
+    cmc2, mAP2 = ops.rank_eval(dist, q_pids, g_pids, q_cams, g_cams)
+    assert abs(mAP2 - 1.0) < 1e-6 and abs(cmc2[0] - 1.0) < 1e-6
+    del dist
+    torch.cuda.empty_cache()

@@ -110,3 +110,197 @@ def test_small_vit_forward_backward_vs_oracle():
     with torch.no_grad():
         e2 = rel_l2(net(x.cuda()).cpu(), OV.build_transformer_forward({k: v.cpu() for k, v in net.state_dict().items()}, x, 2, 16, 16, training=False))
     assert e2 < 3e-2, e2
+
+
+def _droppath_net():
+    """the golden's config (tests/golden/make_golden.py::gen_vit_droppath): 32x32 image, patch 8, dim 64, depth 3, one head, rate 0.5"""
+    from daliid_amd import vit_pytorch as V
+    z = load_golden("vit_droppath.npz")
+    net = V.ViTNeckNet(img_size=(32, 32), patch_size=8, stride_size=8, embed_dim=64, depth=3, num_heads=1, mlp_ratio=4.0, num_classes=10,
+                       drop_path_rate=float(z["rate"]), seed=1)
+    sd = dict(net.state_dict())
+    for k in z.files:
+        if k.startswith("sd/"):
+            sd["base." + k[3:]] = torch.from_numpy(z[k])
+    net.load_state_dict(sd)
+    return net, z
+
+
+def test_droppath_training_matches_reference_with_the_same_draws():
+    """vit_pytorch.py:45-62 / :178-179: the HIP plan fed the uniform draws of the REFERENCE's own train-mode forward (golden) returns the
+    reference's cls feature; gradients against the oracle (itself pinned to the reference's gradients by the same golden)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    net, z = _droppath_net()
+    x, u, w = torch.from_numpy(z["x"]), torch.from_numpy(z["u"]), torch.from_numpy(z["w"])
+    net.train()
+    net.drop_path_uniform = u.cuda()
+    feat, gf = net._run_forward(x.cuda(), True, want_global=True)
+    e = rel_l2(gf.cpu(), torch.from_numpy(z["y"]))
+    print("DropPath train-mode cls feature vs the reference: rel-L2 %.3e" % e)
+    assert e < 2e-2
+    # the dropped samples really lost a branch: without DropPath the result differs by far more than the bf16 noise
+    net.drop_path_uniform = torch.full_like(u, 0.999).cuda()                       # floor(keep + u) = 1 everywhere: nothing dropped, only rescaled
+    _, gf_keep = net._run_forward(x.cuda(), True, want_global=True)
+    assert rel_l2(gf_keep.cpu(), torch.from_numpy(z["y"])) > 5 * e
+    # backward through the post-neck feature
+    net.drop_path_uniform = u.cuda()
+    pnames = {n for n, _ in net.named_parameters()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(k in pnames) for k, v in net.state_dict().items()}
+    ref = OV.build_transformer_forward(sd, x, num_heads=1, patch=8, stride=8, training=True, drop_path=(float(z["rate"]), u))
+    (ref * w).sum().backward()
+    y = net(x.cuda())
+    (y * w.cuda()).sum().backward()
+    assert rel_l2(y.detach().cpu(), ref.detach()) < 3e-2
+    bad = []
+    for name, p in net.named_parameters():
+        if name.startswith("base.fc.") or name == "bottleneck.bias" or name.startswith("base.norm."):
+            continue
+        r = rel_l2(p.grad.cpu(), sd[name].grad)
+        if r >= 8e-2:
+            bad.append((name, r))
+    assert not bad, bad
+    # eval mode ignores DropPath (vit_pytorch.py:58)
+    net.eval()
+    with torch.no_grad():
+        e2 = rel_l2(net(x.cuda()).cpu(), OV.build_transformer_forward({k: v.cpu() for k, v in net.state_dict().items()}, x, 1, 8, 8, training=False))
+    assert e2 < 3e-2
+
+
+def test_droppath_draws_come_from_the_device_generator():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    net, z = _droppath_net()
+    net.train()
+    x = torch.from_numpy(z["x"]).cuda()
+    torch.manual_seed(5); a = net._run_forward(x, True).clone(); sa = net._dp_scales.clone()
+    torch.manual_seed(5); b = net._run_forward(x, True).clone()
+    torch.manual_seed(6); net._run_forward(x, True); sc = net._dp_scales.clone()
+    assert torch.equal(a, b) and not torch.equal(sa, sc)
+    keep = 1 - torch.linspace(0, 0.5, 3).repeat_interleave(2)
+    for i in range(6):
+        vals = set(np.round(sa[i].cpu().numpy(), 5).tolist())
+        assert vals <= {0.0, round(float(1 / keep[i]), 5)}, (i, vals)
+    assert set(sa[0].cpu().tolist()) == {1.0}                                       # block 0 has rate 0: identity (vit_pytorch.py:171)
+
+
+def test_overlapping_patches_211_tokens_forward_backward_vs_oracle():
+    """TransReID's usual person-ReID geometry: 256x128 image, patch 16 at stride 12 -> 21 x 10 patches + cls = 211 tokens
+    (vit_pytorch.py:254-267)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from daliid_amd import vit_pytorch as V
+    net = V.ViTNeckNet(img_size=(256, 128), patch_size=16, stride_size=12, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4.0, num_classes=10, seed=3)
+    assert net.base.pos_embed.shape[1] == 211
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_((0.05 * torch.randn(p.shape, generator=g)).to(p.device))
+    B = 4
+    x = torch.randn(B, 3, 256, 128, generator=g)
+    w = torch.randn(B, 128, generator=g)
+    pnames = {n for n, _ in net.named_parameters()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(k in pnames) for k, v in net.state_dict().items()}
+    ref = OV.build_transformer_forward(sd, x, num_heads=2, patch=16, stride=12, training=True)
+    (ref * w).sum().backward()
+    net.train()
+    y = net(x.cuda())
+    (y * w.cuda()).sum().backward()
+    e = rel_l2(y.detach().cpu(), ref.detach())
+    print("211-token ViT train-mode feat rel-L2 %.3e" % e)
+    assert e < 3e-2
+    bad = []
+    for name, p in net.named_parameters():
+        if name.startswith("base.fc.") or name == "bottleneck.bias" or name.startswith("base.norm."):
+            continue
+        r = rel_l2(p.grad.cpu(), sd[name].grad)
+        if r >= 8e-2:
+            bad.append((name, r))
+    assert not bad, bad
+
+
+def test_frozen_neck_bias_and_unused_fc_are_not_trained():
+    """make_models.py:181 freezes bottleneck.bias; base.fc is never called (grad None): torch.optim.Adam touches neither, weight
+    decay included.  The fused Adam must leave both bit-identical and move every other parameter like torch.optim.Adam."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from daliid_amd import vit_pytorch as V, optim
+    net = V.ViTNeckNet(img_size=(64, 32), patch_size=16, stride_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4.0, num_classes=10, seed=3)
+    with torch.no_grad():
+        net.bottleneck.bias.fill_(0.25)
+        net.base.fc.bias.fill_(0.5)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(6, 3, 64, 32, generator=g)
+    w = torch.randn(6, 128, generator=g)
+    drv = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    fused = optim.FusedAdam.from_torch(drv, net)
+    assert len(fused.ranges) == 2
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    # an independent torch.optim.Adam on clones, fed the plan's gradients
+    clones = {k: torch.nn.Parameter(v.clone()) for k, v in before.items()}
+    ref_opt = torch.optim.Adam([clones[k] for k, p in net.named_parameters() if p.requires_grad and not k.startswith("base.fc.")],
+                               lr=3.5e-4, weight_decay=5e-4)
+    for step in range(3):
+        net.train()
+        y = net(x.cuda())
+        (y * w.cuda()).sum().backward()
+        for k, p in net.named_parameters():
+            if p.requires_grad and not k.startswith("base.fc."):
+                clones[k].grad = p.grad.detach().clone()
+        fused.step()
+        ref_opt.step()
+    for k, p in net.named_parameters():
+        if k == "bottleneck.bias" or k.startswith("base.fc."):
+            assert torch.equal(p.detach(), before[k]), k
+        else:
+            assert not torch.equal(p.detach(), before[k]), k
+            np.testing.assert_allclose(p.detach().cpu().numpy(), clones[k].detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=k)
+    total = sum(float(p.detach().double().pow(2).sum()) for p in net.parameters())
+    assert np.isclose(fused.weights_sqsum.item(), total, rtol=1e-5)               # the trainer's weights_sum runs over ALL parameters
+
+
+def test_configs3_full_step_batch128_properties():
+    """configs[3]: one full TransReID ViT-B/16 train step at batch 128 with the reference's default drop_path_rate 0.1 (vit_pytorch.py:453):
+    finite, bit-reproducible from the same state, Adam-sized update, frozen / unused parameters untouched."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from daliid_amd import vit_pytorch as V
+    from daliid_amd.losses import LossHeads, _sample_weights
+    from daliid_amd.ops_eval import l2norm_rows
+    from daliid_amd.train_encodersKIT import trainer
+    dev = torch.device("cuda", 0)
+    B, NC, D = 128, 64, 768
+    gen = torch.Generator(device=dev).manual_seed(12)
+    imgs = torch.randn(B, 3, 224, 224, device=dev, generator=gen)
+    centers = l2norm_rows(torch.randn(NC, D, device=dev, generator=gen))
+    proxies = l2norm_rows(torch.randn(5 * NC, D, device=dev, generator=gen))
+    labels = torch.arange(B // 16, device=dev).repeat_interleave(16).to(torch.int32)
+    w = _sample_weights(torch.randint(0, 6, (B,)), 10, 250, dev)
+    u = torch.rand(24, B, device=dev, generator=gen)
+    results = []
+    for rep in range(2):
+        mk = lambda: V.ViTNeckNet(img_size=(224, 224), patch_size=16, stride_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                                  drop_path_rate=0.1, device=dev, seed=12)
+        online, momentum = mk(), mk()
+        online.drop_path_uniform = u
+        drv = torch.optim.Adam([p for p in online.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+        tr = trainer("Synthetic", None, "vit_base", {}, 224, 224, None, False, 1, drv, B // 16, 16, 0.05, 0.999, 0.4, 250, online, momentum, [0], "t")
+        heads = LossHeads(centers, np.arange(NC), proxies, np.repeat(np.arange(NC), 5), 0.05, 0.4)
+        online.train(); momentum.eval()
+        before = online.flat_params.clone()
+        acc = torch.zeros(6, device=dev)
+        tr.train_step(heads, imgs, labels, w, acc)
+        torch.cuda.synchronize()
+        results.append((online.flat_params.clone(), online.flat_grads.clone(), acc.clone(), momentum.flat_params.clone()))
+        moved = (online.flat_params - before).abs()
+        assert torch.isfinite(online.flat_params).all() and torch.isfinite(online.flat_grads).all() and torch.isfinite(acc).all()
+        assert 1e-4 < float(moved.max()) < 1.2e-3                                    # first Adam step moves by ~lr
+        assert float((online.flat_grads != 0).float().mean()) > 0.9
+        assert torch.equal(online.bottleneck.bias.detach(), torch.zeros_like(online.bottleneck.bias))
+        fc0 = V.ViTNeckNet(img_size=(224, 224), device=dev, seed=12).base.fc.weight if rep == 0 else None
+        if fc0 is not None:
+            assert torch.equal(online.base.fc.weight.detach(), fc0.detach())
+        del online, momentum, tr, heads
+        torch.cuda.empty_cache()
+    for a, b in zip(results[0], results[1]):
+        assert torch.equal(a, b)                                                     # deterministic reductions: bit-reproducible

@@ -80,7 +80,8 @@ def test_layernorm_fwd_bwd(V, rows, C):
     np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), rtol=2e-3, atol=2e-3 * float(br.grad.abs().max()))
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 197, 12), (3, 50, 2), (1, 208, 1), (2, 129, 4)])
+# 211 tokens = TransReID at 256x128 / stride 12 (vit_pytorch.py:254-267); 209..224 run the 14-tile instance, 225..256 the 16-tile one
+@pytest.mark.parametrize("B,T,H", [(2, 197, 12), (3, 50, 2), (1, 208, 1), (2, 129, 4), (2, 211, 12), (1, 224, 2), (2, 240, 1), (1, 256, 3)])
 def test_attention_fwd_bwd(V, B, T, H):
     g = torch.Generator().manual_seed(B * 1000 + T + H)
     C = H * 64

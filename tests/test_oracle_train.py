@@ -84,3 +84,21 @@ def test_vit_tiny_forward_backward_matches_reference():
     for k in z.files:
         if k.startswith("tiny/grad/"):
             np.testing.assert_allclose(sd[k[len("tiny/grad/"):]].grad.numpy(), z[k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_vit_droppath_matches_reference_train_mode():
+    """DropPath (vit_pytorch.py:45-62): the oracle fed the uniform draws the reference's forward consumed reproduces the
+    reference's train-mode output and every parameter gradient; with other draws it does not (the draws matter)."""
+    z = load_golden("vit_droppath.npz")
+    sd = {k[len("sd/"):]: torch.from_numpy(z[k]).requires_grad_(True) for k in z.files if k.startswith("sd/")}
+    x, u, rate = torch.from_numpy(z["x"]), torch.from_numpy(z["u"]), float(z["rate"])
+    y = OV.transreid_forward(sd, x, num_heads=1, patch=8, stride=8, drop_path=(rate, u))
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=1e-5, atol=1e-6)
+    (y * torch.from_numpy(z["w"])).sum().backward()
+    n = 0
+    for k in z.files:
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(sd[k[len("grad/"):]].grad.numpy(), z[k], rtol=2e-4, atol=2e-6, err_msg=k); n += 1
+    assert n > 30
+    y0 = OV.transreid_forward(sd, x, num_heads=1, patch=8, stride=8)            # no DropPath: a different function
+    assert float((y0.detach() - torch.from_numpy(z["y"])).abs().max()) > 1e-3
