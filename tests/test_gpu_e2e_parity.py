@@ -9,7 +9,8 @@ path, as in a trained net) and structured synthetic person images (a low-frequen
      required to add nothing beyond that (and the absolute numbers are printed).
 (ii) the north star's accuracy statement: identical weights in the fp32 CPU oracle (eval) and in the HIP net -> each side's OWN
      features -> own normalise + distance -> own market1501 ranking on 200 synthetic identities: |mAP difference| < 1e-3, CMC within
-     1/Nq (Encoders.py:330-351, validateModels.py:35-58)."""
+     1/Nq on separated identities; on a hard ranking problem the tolerance is the one fp32 noise of the same size produces
+     (Encoders.py:330-351, validateModels.py:35-58)."""
 import copy
 
 import numpy as np
@@ -102,7 +103,12 @@ def test_full_resnet50_train_mode_vs_fp32_oracle(nets):
     assert hip_fp32 < 9e-2 and np.median(list(c_fp32.values())) > 0.88 and min(c_fp32.values()) > 0.7
 
 
-def test_map_cmc_own_features_vs_fp32_oracle(nets):
+@pytest.mark.parametrize("noise,map_tol,cmc_slack", [(1.4, 1e-3, 1), (1.9, 1.5e-2, 4)])
+def test_map_cmc_own_features_vs_fp32_oracle(nets, noise, map_tol, cmc_slack):
+    """noise 1.4: separated identities (oracle mAP ~0.98): the north star's |mAP difference| < 1e-3, CMC within 1/Nq.
+    noise 1.9: a hard ranking problem (oracle mAP ~0.81).  There the statement cannot hold for bf16 features and the tolerance says so:
+    perturbing the ORACLE's own fp32 features by 7e-3 relative Gaussian noise (the measured eval-mode bf16-vs-fp32 embedding error)
+    moves its mAP by 4e-3 ... 1.5e-2 and its CMC by 2-4 queries (5 draws, CPU, 200 queries) -- near-tied gallery entries swap."""
     ref, net = nets
     ref = copy.deepcopy(ref).eval()
     net.eval()
@@ -110,7 +116,7 @@ def test_map_cmc_own_features_vs_fp32_oracle(nets):
     n_ids, per_id, H, W = 200, 4, 256, 128
     pids = np.repeat(np.arange(n_ids), per_id)
     cams = np.tile(np.arange(per_id), n_ids) % 3
-    x = person_images(pids, H, W, 7, noise=1.2)
+    x = person_images(pids, H, W, 7, noise=noise)
     is_q = (np.tile(np.arange(per_id), n_ids) == per_id - 1)
     with torch.no_grad():
         f_ref = torch.cat([ref(x[i:i + 50]) for i in range(0, len(pids), 50)])
@@ -122,9 +128,9 @@ def test_map_cmc_own_features_vs_fp32_oracle(nets):
     from daliid_amd import ops_eval
     d_hip = ops_eval.pairdist(f_hip[torch.from_numpy(is_q).cuda()].contiguous(), f_hip[torch.from_numpy(~is_q).cuda()].contiguous(), normalize=True)
     cmc, mAP = ops_eval.rank_eval(d_hip, qp, gp, qc, gc)
-    print("eval-mode embedding rel-L2 vs fp32 %.3e; mAP HIP %.5f vs oracle %.5f (diff %.2e); rank-1 %.4f vs %.4f"
-          % (e, mAP, map_ref, abs(mAP - map_ref), cmc[0], cmc_ref[0]))
-    assert 0.05 < map_ref < 0.995                                                # a ranking problem that can move
+    print("noise %.1f: eval-mode embedding rel-L2 vs fp32 %.3e; mAP HIP %.5f vs oracle %.5f (diff %.2e); rank-1 %.4f vs %.4f; max CMC diff %.4f"
+          % (noise, e, mAP, map_ref, abs(mAP - map_ref), cmc[0], cmc_ref[0], np.abs(cmc - cmc_ref).max()))
+    assert 0.05 < map_ref < 0.9999                                               # a ranking problem that can move
     assert e < 2e-2
-    assert abs(mAP - map_ref) < 1e-3
-    assert np.abs(cmc - cmc_ref).max() <= 1.0 / is_q.sum() + 1e-6
+    assert abs(mAP - map_ref) < map_tol
+    assert np.abs(cmc - cmc_ref).max() <= cmc_slack / is_q.sum() + 1e-6
