@@ -4,9 +4,9 @@ path, as in a trained net) and structured synthetic person images (a low-frequen
 
 (i)  train mode, batch 32, 256x128: embedding and every parameter gradient vs the fp32 oracle, with the ROUNDING-MATCHED fp32 twin
      (oracle/resnet50_bf16.py: fp32 arithmetic, bf16 round trips exactly where the kernels store bf16) measured beside it.
-     Measured in the build container for the twin alone (no GPU involved): embedding rel-L2 5.7e-2 from fp32, median gradient
-     cosine 0.92, i.e. ANY implementation that stores these activations in bf16 sits that far from fp32 on this net; the HIP path is
-     required to add nothing beyond that (and the absolute numbers are printed).
+     Measured for the twin alone (CPU, no GPU involved): embedding rel-L2 6.0e-2 from fp32, parameter-gradient cosine min 0.875 /
+     median 0.919, i.e. ANY implementation that stores these activations in bf16 sits that far from fp32 on this net; the HIP path
+     measured 5.97e-2 and 0.870 / 0.917 on MI355X (round 2): it is required to add nothing beyond the twin (numbers are printed).
 (ii) the north star's accuracy statement: identical weights in the fp32 CPU oracle (eval) and in the HIP net -> each side's OWN
      features -> own normalise + distance -> own market1501 ranking on 200 synthetic identities: |mAP difference| < 1e-3, CMC within
      1/Nq on separated identities; on a hard ranking problem the tolerance is the one fp32 noise of the same size produces
@@ -111,6 +111,7 @@ def test_map_cmc_own_features_vs_fp32_oracle(nets, noise, map_tol, cmc_slack):
     moves its mAP by 4e-3 ... 1.5e-2 and its CMC by 2-4 queries (5 draws, CPU, 200 queries) -- near-tied gallery entries swap."""
     ref, net = nets
     ref = copy.deepcopy(ref).eval()
+    net.load_state_dict(ref.state_dict())           # the train-mode test above has moved the HIP net's running statistics
     net.eval()
     torch.set_num_threads(max(torch.get_num_threads(), 8))
     n_ids, per_id, H, W = 200, 4, 256, 128
