@@ -175,6 +175,11 @@ __device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, unsigned bits) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 1, 1) << 16;         // 0 or 0xffff0000
     return w & (lo | hi);
 }
+// bit 0 / bit 1: the low / high bf16 half of w is > 0
+__device__ __forceinline__ unsigned pos_bits_bf16x2(uint32_t w) {
+    return ((int)(int16_t)(w & 0xffffu) > 0 ? 1u : 0u) | (((int)w >> 16) > 0 ? 2u : 0u);
+}
+// LIN: 3 = the fused output stage (IGemmArgs::out_scale ... out_mask) in a staged block and in the general path;
 // LIN: 0 = a convolution-only instantiation (no linear-layer extras compiled in at all), 1 = extras in the staged block and in the
 // general path (the LIN kernel variants), 2 = extras in the general path only (kernels without a LIN variant)
 template <int TM, int TN, int FM_, int FN_, int WNW, int NT, int LIN = 2>
@@ -220,7 +225,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 5] = __builtin_amdgcn_s_memrealtime();     // stats done
 
     // ---- lean path: plain convolution (optionally + residual), interior tile, natural output addressing ----
-    const bool plain = !a.O2 && a.act == 0 && !a.dact_pre && !a.g.sub && (a.Cm & 7) == 0;      // bias (linear layers) is folded in below
+    const bool plain = LIN != 3 && !a.O2 && a.act == 0 && !a.dact_pre && !a.g.sub && (a.Cm & 7) == 0;      // bias (linear layers) is folded in below
     // the linear layers' GELU / pre-activation copy (O2) / GELU' factor take a second staged block further down, kept apart so that the
     // convolutions' path stays as lean as it was (folding them into one block cost the ResNet step 0.8 ms)
     // (only in the LIN instantiations of the kernels: compiled into every kernel it changed the convolutions' register allocation and
@@ -375,6 +380,75 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         return;
     }
 
+    if constexpr (LIN == 3) if (interior && !a.g.sub && (a.Cm & 7) == 0) {     // fused output stage (see IGemmArgs): staged like the lean path
+        constexpr int ROWB = TM * 2 + 32;
+        constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
+        static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
+        char* stage = reinterpret_cast<char*>(smem);
+        char* my_stage = stage + (wn * WROWS + (lane & 15)) * ROWB + mb * 2;
+        const int ch = threadIdx.x % CPR, lp0 = threadIdx.x / CPR;
+        float4 sc4[Cfg::FM], sh4[Cfg::FM];
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i) {
+            const int c = tm * TM + mb + i * 16;
+            sc4[i] = a.out_scale ? *reinterpret_cast<const float4*>(a.out_scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            sh4[i] = a.out_shift ? *reinterpret_cast<const float4*>(a.out_shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + c); sh4[i].x += b.x; sh4[i].y += b.y; sh4[i].z += b.z; sh4[i].w += b.w; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
+            if (a.Res) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lp = lp0 + it * (NT / CPR);
+                    const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
+                    const size_t rb = gbase + (size_t)q * a.Cm * 2;
+                    uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
+                    if (a.res_mask) {
+                        const unsigned m = a.res_mask[rb >> 4];
+                        rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
+                    }
+                    *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) = rv;
+                }
+                lds_barrier_vm();
+            }
+#pragma unroll
+            for (int jj = 0; jj < HFN; ++jj) {
+                const int j = h * HFN + jj;
+#pragma unroll
+                for (int i = 0; i < Cfg::FM; ++i) {
+                    float v0 = acc[i][j][0] * sc4[i].x + sh4[i].x, v1 = acc[i][j][1] * sc4[i].y + sh4[i].y;
+                    float v2 = acc[i][j][2] * sc4[i].z + sh4[i].z, v3 = acc[i][j][3] * sc4[i].w + sh4[i].w;
+                    uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
+                    if (a.Res) {
+                        const uint2 rv = *slot;
+                        v0 += bf16_bits_to_f32(rv.x & 0xffffu); v1 += bf16_bits_to_f32(rv.x >> 16);
+                        v2 += bf16_bits_to_f32(rv.y & 0xffffu); v3 += bf16_bits_to_f32(rv.y >> 16);
+                    }
+                    if (a.out_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    *slot = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int lp = lp0 + it * (NT / CPR);
+                const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
+                const size_t ob = gbase + (size_t)q * a.Cm * 2;
+                uint4 v = *reinterpret_cast<const uint4*>(stage + lp * ROWB + ch * 16);
+                if (a.out_mask) {
+                    const unsigned m = a.out_mask[ob >> 4];
+                    v.x = gate_bf16x2(v.x, m); v.y = gate_bf16x2(v.y, m >> 2); v.z = gate_bf16x2(v.z, m >> 4); v.w = gate_bf16x2(v.w, m >> 6);
+                }
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O) + ob) = v;
+                if (a.bits_out) a.bits_out[ob >> 4] = (uint8_t)(pos_bits_bf16x2(v.x) | (pos_bits_bf16x2(v.y) << 2) | (pos_bits_bf16x2(v.z) << 4) | (pos_bits_bf16x2(v.w) << 6));
+            }
+            if (h == 0) lds_barrier();
+        }
+        return;
+    }
+
     // ---- general path: edge tiles, linear-layer epilogues (bias / GELU / GELU' / second output), parity sub-problems ----
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
@@ -383,14 +457,19 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
 #pragma unroll
         for (int i = 0; i < Cfg::FM; ++i) {
             const int c = tm * TM + mb + i * 16;
+            unsigned nib = 0;
             if (p < a.P && c < a.Cm) {      // Cm is a multiple of 4: the 4 channels are all valid
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const size_t o = opix * a.Cm + c;
+                if constexpr (LIN == 3) {
+                    if (a.out_scale) { const float4 sv = *reinterpret_cast<const float4*>(a.out_scale + c); v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w; }
+                    if (a.out_shift) { const float4 sv = *reinterpret_cast<const float4*>(a.out_shift + c); v[0] += sv.x; v[1] += sv.y; v[2] += sv.z; v[3] += sv.w; }
+                }
                 if (a.bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
-                if constexpr (LIN != 0) {
+                if constexpr (LIN == 1 || LIN == 2) {
                 if (a.O2) *reinterpret_cast<uint2*>(a.O2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 if (a.act == 1) {
 #pragma unroll
@@ -414,7 +493,21 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
                     v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
                 }
-                *reinterpret_cast<uint2*>(a.O + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                uint2 ov = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                if constexpr (LIN == 3) {
+                    if (a.out_relu) ov = make_uint2(pack_bf16x2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), pack_bf16x2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)));
+                    if (a.out_mask) {
+                        const unsigned m = a.out_mask[o >> 3] >> (o & 4);
+                        ov.x = gate_bf16x2(ov.x, m); ov.y = gate_bf16x2(ov.y, m >> 2);
+                    }
+                    nib = pos_bits_bf16x2(ov.x) | (pos_bits_bf16x2(ov.y) << 2);
+                }
+                *reinterpret_cast<uint2*>(a.O + o) = ov;
+            }
+            if constexpr (LIN == 3) {
+                // this lane's 4 mask bits and those of lane ^ 16 (the other half of the same byte: Cm % 8 == 0 is required) -> one byte store
+                const unsigned other = __shfl_xor(nib, 16, 64);
+                if (a.bits_out && p < a.P && c < a.Cm && ((lane >> 4) & 1) == 0) a.bits_out[(opix * a.Cm + c) >> 3] = (uint8_t)(nib | (other << 4));
             }
         }
     }
@@ -456,7 +549,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
 // ------------------------------------------------------------------------------------------------
 // (lds_void_ptr, DMA_OOB, dma_wait<N> live in gemm_tile.h: shared with eval.hip)
 
-template <int TM, int TN, int NSTAGE, bool LIN = false>
+template <int TM, int TN, int NSTAGE, int EPI = 0>        // EPI: 0 convolution, 1 linear-layer extras, 3 fused output stage (conv_epilogue_g)
 __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     // 128 x 128: <= 128 VGPRs (4 waves per SIMD); the 64 x 256 shape carries twice the per-lane gather state and would spill
     using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
@@ -580,7 +673,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kerne
     __syncthreads();
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
 
-    conv_epilogue<Cfg, (TM == 128 && TN == 128 && NSTAGE == 3) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem);
+    conv_epilogue<Cfg, (TM == 128 && TN == 128 && NSTAGE == 3) ? EPI : 2>(a, acc, tm, tn, smem);
     if (a.stamps) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();   // all stores issued (not yet acknowledged)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have been acknowledged
@@ -595,7 +688,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kerne
 // budget as the 128 x 128 kernel), block tile (64*WM) x (64*WN).  256 x 256 with 16 waves halves the L2->LDS bytes per
 // FLOP (measured limiter of the 128 x 128 kernel: ~47 GB/s per CU of operand traffic at 0.8 PFLOP/s) and leaves room
 // for a 4-deep LDS ring (3 k-tiles in flight) at one block per CU.
-template <int WM, int WN, int NSTAGE, bool LIN = false>
+template <int WM, int WN, int NSTAGE, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN, NT = NW * 64;
     constexpr int A_BLK = TM / 16 / NW, B_BLK = TN / 16 / NW, NDMA = A_BLK + B_BLK;
@@ -708,7 +801,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
         st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
     }
     __syncthreads();
-    conv_epilogue_g<TM, TN, 4, 4, WN, NT, (WM == 2 && WN == 4 && NSTAGE == 3) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, 4, 4, WN, NT, (WM == 2 && WN == 4 && NSTAGE == 3) ? EPI : 2>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -721,7 +814,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
 // logical chunk ^ ((row >> 1) & 7): every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ... = 8 rows of one
 // chunk + 8 rows of the next) lands on 16 distinct 16-byte bank slots.  Needs Ck % 64 == 0.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4, bool LIN = false>
+template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NW = WM * WN, NT = NW * 64;     // per-wave sub-tile 16 FM x 16 FN
     constexpr int A_BLK = TM / 8 / NW, B_BLK = TN / 8 / NW, NDMA = A_BLK + B_BLK;
@@ -831,7 +924,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
         st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
     }
     __syncthreads();
-    conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 4 && WN == 4 && NSTAGE == 2 && FM == 4) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 4 && WN == 4 && NSTAGE == 2 && FM == 4) ? EPI : 2>(a, acc, tm, tn, smem, wm, wn);
 }
 
 // Wave-specialised k-tile-64 kernel: WM x WN consumer waves (64 x 64 sub-tiles: fragment reads + MFMAs + epilogue) and NP
@@ -1898,7 +1991,32 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
     if (k64_min_k < 0) { const char* e = getenv("DALI_CONV_K64_MINK"); k64_min_k = e ? atoi(e) : 1024; }
     if ((k64 == 2 || k64 == 6) && !(K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
-    if (k64 && cfg == CONV_256x256) {
+    // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
+    // instantiations compile none of it (code that is never executed still cost their register allocation 0.4-0.8 ms per step)
+    const bool fused = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask;
+    if (fused) {
+        if (in_bn || !dma_ok || (a.Cm & 7) || lin) {
+            set_error("conv: the fused output stage needs Cm %% 8 == 0, tensors below 2 GiB, no operand transform and no linear-layer extras");
+            return DALI_ERR_INVALID;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 256) * 64 * 2 * 2));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 256) * 32 * 2 * 3));
+            attr_set = true;
+        }
+        if (k64 && cfg == CONV_256x256) {
+            const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
+            hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
+        } else if (cfg == CONV_128x256 || cfg == CONV_256x256) {
+            const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
+            hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), (128 + 256) * 32 * 2 * 3, st, args, tiles_m, tiles_n);
+        } else {
+            using Cfg = GemmCfg<128, 128, 1, 1, 1>;
+            const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
+            hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
+        }
+    } else if (k64 && cfg == CONV_256x256) {
         static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
         const int lds = (256 + 256) * 64 * 2 * 2;

@@ -37,6 +37,16 @@ struct IGemmArgs {
     int Cm, P, in_relu;
     GatherGeom g;
     unsigned long long* stamps;   // diagnostic (dali_debug_set_conv_stamps): [block][12] s_memrealtime stamps (see scripts/conv_block_timeline.py)
+    // ---- fused output stage (the EPI = 3 kernel instantiations; all optional) ----
+    // value = acc * out_scale[c] + out_shift[c] (+ Res) -> ReLU if out_relu -> gated by out_mask -> O; bits_out gets (value > 0).
+    // Forward: the BatchNorm of a 1x1 convolution whose batch statistics were derived from the Gram matrix of its input BEFORE the
+    // GEMM ran (bnlin.hip), so that y = relu(bn(conv(x)) + identity) leaves the GEMM directly and the raw conv output is never stored.
+    // Backward: out_mask = ReLU mask of the block output this gradient belongs to, so that dz = dy * (y > 0) is what is stored.
+    const float* out_scale;   // [Cm]
+    const float* out_shift;   // [Cm]
+    int out_relu;
+    uint8_t* bits_out;        // 1 bit per output element, bit e & 7 of byte e >> 3, e = p*Cm + c (the layout of res_mask)
+    const uint8_t* out_mask;  // same layout
 };
 
 struct WGradArgs {
