@@ -2202,6 +2202,7 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     }
     DALI_LAUNCH_CHECK();
+    if (!out) return DALI_OK;                       // the caller reduces the slabs itself
     const size_t elems = (size_t)a.Cm * a.Ntot, chunks = (elems + 3) / 4;
     const unsigned rblocks = (unsigned)((chunks + 63) / 64);
     if (a.splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(rblocks), dim3(1024), 0, st, a.partial, out, elems, a.splits, accumulate);
@@ -2319,6 +2320,21 @@ extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
 }
 
 // ---- Linear layers (ViT: qkv / proj / fc1 / fc2 / patch embedding) on the same engine: a Linear is a 1x1 conv over tokens ----
+// 1x1 convolution with the fused output stage (IGemmArgs::out_scale ...): y = gate(relu?(acc*out_scale + out_shift + bias + residual)),
+// bits_out = (y > 0).  mode 0: forward (w [cout][cin]); mode 1: data gradient (w = the [cin][cout] image, x = dy).
+extern "C" int dali_conv1x1_fused(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y, int pixels, int cin, int cout,
+                                  const float* out_scale, const float* out_shift, const float* bias, const uint16_t* residual, int out_relu,
+                                  uint8_t* bits_out, const uint8_t* out_mask) {
+    DALI_REQUIRE(ctx && x && w && y, "dali_conv1x1_fused: null argument");
+    DALI_REQUIRE(cin % 32 == 0 && cout % 8 == 0 && pixels > 0, "dali_conv1x1_fused: cin %% 32, cout %% 8 (cin=%d cout=%d)", cin, cout);
+    IGemmArgs a{};
+    a.W = w; a.X = x; a.O = y; a.Res = residual; a.bias = bias;
+    a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu; a.bits_out = bits_out; a.out_mask = out_mask;
+    a.Cm = cout; a.P = pixels;
+    fill_geom(a.g, 1, 1, pixels, cin, 1, pixels, 1, 1, 1, 0, 0);
+    return launch_igemm_conv((hipStream_t)stream, a);
+}
+
 static void linear_geom(GatherGeom& g, int K) {
     g.Hout = 1; g.Wout = 1; g.Hin = 1; g.Win = 1; g.Ck = K; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.mode = 0;
     g.pix_pitch = K; g.row_pitch = K; g.img_pitch = K; g.lw = g.lhw = -1;

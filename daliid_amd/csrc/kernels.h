@@ -73,12 +73,23 @@ int igemm_conv_stat_tiles(int Cm, int P, int K);
 // taps = R*S of the convolution (1 for 1x1 convolutions and linear layers): selects the tile shape
 // halo_w = output width of a 3x3 / stride 1 / pad 1 convolution whose H*W is a power of two (0 otherwise): enables the halo kernel
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps = 1, int halo_w = 0);
+// out == nullptr: leave the split-K slabs in a.partial ([splits][Cm][Ntot]) for the caller to reduce (bnlin.hip)
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
 
 int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,
                       uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N);
 int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab);
 size_t linear_wgrad_slab_bytes(int rows, int K, int N);
+
+// bnlin.hip: BatchNorm behind a 1x1 convolution from the moments of the convolution's INPUT (no raw conv output is stored)
+//   forward : scale / shift / mean / invstd of raw = a W^T from gram = a^T a [w][w] and m2 = colsum(a) [w]  (W bf16 [C][w])
+//   backward: split-K slabs of G0 = dz^T a (+ s_dz = colsum(dz)) -> dW [C][w], dgamma, dbeta, and the two data-gradient weight images
+//             wd1 = (A.W)^T [w][C], wd2 = -(W^T diag(Q) W) [w][w] with bvec = W^T Kc [w]; qk [2][C] is scratch
+int launch_bnlin_stats(hipStream_t st, const uint16_t* W, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
+                       const float* beta, float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd);
+int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* gram, const float* m2, const float* s_dz, int C,
+                     int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
+                     uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk);
 
 // nnops.hip
 constexpr int REDUCE_SMAX = 64;        // rows of the fp64 second-level scratch
@@ -106,7 +117,8 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
                           const float* scale, int N, int H, int W, int C, float* partial, float* coef, float* dgamma, float* dbeta,
                           uint16_t* draw, double* scratch);
 int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C, int mode, float* f, int16_t* arg);
-int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, int mode, uint16_t* dx);
+// ybits (nullable): ReLU mask of the tensor the gradient belongs to; the masked gradient dz = dy * (y > 0) is what is written
+int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, int mode, uint16_t* dx, const uint8_t* ybits = nullptr);
 int launch_bn1d_fwd(hipStream_t st, const float* x, int N, int C, const float* gamma, const float* beta, float* rm, float* rv, int training,
                     float momentum, float eps, float* y, float* mean, float* invstd);
 int launch_bn1d_bwd(hipStream_t st, const float* x, const float* dy, int N, int C, const float* gamma, const float* mean, const float* invstd,

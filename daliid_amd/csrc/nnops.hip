@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void head_pool_fwd_kernel(const uint16_t* __re
     }
 }
 __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restrict__ df, const int16_t* __restrict__ arg, int N, int HW,
-                                                             int C, int mode, uint16_t* __restrict__ dx) {
+                                                             int C, int mode, uint16_t* __restrict__ dx, const uint8_t* __restrict__ ybits) {
     const int cpr = C >> 3;
     const unsigned total = (unsigned)N * HW * cpr;              // < 2^32 (checked by the launcher): 32-bit index arithmetic
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -669,6 +669,11 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const float* __restr
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             o[t] = (mode == DALI_FEATURE_GMP ? 0.f : g[t] / (float)HW) + ((mode != DALI_FEATURE_GAP && a[t] == p) ? g[t] : 0.f);
+        if (ybits) {                                  // dz = dy * (y > 0): the block's BatchNorm backward consumes the masked gradient
+            const unsigned m = ybits[((size_t)pix * C + cc) >> 3];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = ((m >> t) & 1u) ? o[t] : 0.f;
+        }
         *reinterpret_cast<uint4*>(dx + (size_t)pix * C + cc) = pack8(o);
     }
 }
@@ -982,9 +987,9 @@ int launch_head_pool_fwd(hipStream_t st, const uint16_t* x, int N, int HW, int C
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, int mode, uint16_t* dx) {
+int launch_head_pool_bwd(hipStream_t st, const float* df, const int16_t* arg, int N, int HW, int C, int mode, uint16_t* dx, const uint8_t* ybits) {
     if ((long long)N * HW * (C / 8) >= (1ll << 32)) { set_error("head_pool_bwd: more than 2^32 16-byte chunks"); return DALI_ERR_LIMIT; }
-    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, st, df, arg, N, HW, C, mode, dx);
+    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(grid_for((size_t)N * HW * (C / 8))), dim3(256), 0, st, df, arg, N, HW, C, mode, dx, ybits);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }

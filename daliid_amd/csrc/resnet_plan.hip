@@ -40,7 +40,12 @@ struct Block {
     int hin, win, hout, wout, cin, width, cout;
     uint8_t* ybits = nullptr;                                  // ReLU mask of y, one bit per element (dali_bn_act mask_out)
     uint16_t *x, *raw1, *a1, *raw2, *a2, *raw3, *rawd, *y;    // a = relu(bn(raw)), materialised once (fused
-};                                                              // apply-on-load repeats the VALU work per tap and per M-tile)
+                                                                // apply-on-load repeats the VALU work per tap and per M-tile)
+    // bn3 behind conv3 through the moments of a2 (bnlin.hip): blocks without a downsample branch never store raw3
+    bool lin3 = false;
+    float *gram = nullptr, *m2 = nullptr, *sdz = nullptr, *bvec = nullptr, *qk = nullptr;      // [w][w], [w], [cout], [w], [2][cout]
+    uint16_t* wd2 = nullptr;                                   // [w][w] second data-gradient image; the first one lives in c3.wt_bf16
+};
 
 struct Arena {
     size_t used = 0;
@@ -66,7 +71,7 @@ struct dali_resnet {
     uint16_t *ximg = nullptr, *raw0 = nullptr, *pool0 = nullptr, *w_stem = nullptr;
     uint8_t* pool_arg = nullptr;
     float *feat = nullptr, *emb_in = nullptr, *stat_partial = nullptr, *bwd_partial = nullptr, *wgrad_slab = nullptr, *stem_dw_pad = nullptr;
-    float *dfeat = nullptr, *neck_mean = nullptr, *neck_invstd = nullptr;
+    float *dfeat = nullptr, *neck_mean = nullptr, *neck_invstd = nullptr, *cs_partial = nullptr;
     double* red_scratch = nullptr;
     int16_t* head_arg = nullptr;
     uint16_t* gbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -139,6 +144,18 @@ GatherGeom conv_geom(const Conv& c, int mode) {
     g.lw = g.lhw = -1;
     return g;
 }
+// DALI_BNLIN=0 (A/B aid): every block keeps the materialised form (raw3 stored, bn_act, two-pass BatchNorm backward)
+bool bnlin_on() {
+    static int v = -1;
+    if (v == -1) { const char* e = getenv("DALI_BNLIN"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+// a cin = cout = w 1x1 convolution on the grid of conv3: the shape of the Gram GEMM a2^T a2 and of the second data-gradient GEMM
+Conv square_conv(const Conv& c3) {
+    Conv q = c3;
+    q.cin = c3.cin; q.cout = c3.cin; q.w_off = 0; q.w_bf16 = nullptr; q.wt_bf16 = nullptr;
+    return q;
+}
 // the stem reads the packed [N][H+6][W+8][4] image: one tap row (8 taps x 4 ch) per k-tile
 GatherGeom stem_geom(const dali_resnet* net) {
     GatherGeom g{};
@@ -190,6 +207,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
                 add_bn(net, b.bd, pre + ".downsample.1", planes * 4);
             }
             b.hout = b.c2.hout; b.wout = b.c2.wout;
+            b.lin3 = !b.has_ds && bnlin_on() && planes % 8 == 0;
             h = b.hout; w = b.wout; inpl = planes * 4;
             net->blocks.push_back(b);
         }
@@ -213,7 +231,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     reserve_bn(net, a, net->stem_bn);
     size_t max_act = raw0_bytes, max_stat = (size_t)igemm_conv_stat_tiles(wb, (int)N * net->stem_h * net->stem_w, 224) * wb * 2 * 4;
     size_t max_bwd_partial = bn_bwd_partial_floats((int)N * net->stem_h * net->stem_w, wb, false) * 4;
-    size_t max_slab = 0;
+    size_t max_slab = 0, max_cs = 256;
     {
         int sp, pps; size_t wsb;
         wgrad_plan(wb, 224, (int)N * net->stem_h * net->stem_w, 512, &sp, &pps, &wsb);
@@ -225,7 +243,16 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
         reserve(net, a, b.a1, pin * b.width * 2);
         reserve(net, a, b.raw2, pout * b.width * 2);
         reserve(net, a, b.a2, pout * b.width * 2);
-        reserve(net, a, b.raw3, pout * b.cout * 2);
+        if (!b.lin3) reserve(net, a, b.raw3, pout * b.cout * 2);
+        else {
+            reserve(net, a, b.gram, (size_t)b.width * b.width * 4); reserve(net, a, b.m2, (size_t)b.width * 4);
+            reserve(net, a, b.sdz, (size_t)b.cout * 4); reserve(net, a, b.bvec, (size_t)b.width * 4); reserve(net, a, b.qk, (size_t)b.cout * 8);
+            reserve(net, a, b.wd2, (size_t)b.width * b.width * 2);
+            max_cs = std::max(max_cs, std::max(colsum_partial_floats((int)pout, b.cout), colsum_partial_floats((int)pout, b.width)) * 4);
+            int sp, pps; size_t wsb;
+            wgrad_plan(b.width, b.width, (int)pout, 512, &sp, &pps, &wsb, 1, 0);
+            max_slab = std::max(max_slab, wsb);
+        }
         reserve(net, a, b.y, pout * b.cout * 2);
         reserve(net, a, b.ybits, pout * b.cout / 8);
         if (b.has_ds) reserve(net, a, b.rawd, pout * b.cout * 2);
@@ -253,6 +280,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     reserve(net, a, net->stat_partial, max_stat);
     reserve(net, a, net->bwd_partial, max_bwd_partial);
     reserve(net, a, net->wgrad_slab, max_slab);
+    reserve(net, a, net->cs_partial, max_cs);
     reserve(net, a, net->stem_dw_pad, (size_t)wb * 224 * 4);
     reserve(net, a, net->red_scratch, reduce_scratch_bytes(net->feat_dim, 3));
     for (int i = 0; i < 6; ++i) reserve(net, a, net->gbuf[i], max_act);
@@ -324,7 +352,7 @@ extern "C" int dali_resnet_refresh_weights(dali_resnet* net, void* stream) {
     if (rc) return rc;
     std::vector<TransposeJob> jobs;                      // every conv's dgrad image [cin][r*s][cout], one launch
     for (auto& b : net->blocks) {
-        Conv* cs[4] = {&b.c1, &b.c2, &b.c3, b.has_ds ? &b.cd : nullptr};
+        Conv* cs[4] = {&b.c1, &b.c2, b.lin3 ? nullptr : &b.c3, b.has_ds ? &b.cd : nullptr};      // lin3: c3's data-gradient image is built per step (A.W3)
         for (Conv* c : cs)
             if (c) jobs.push_back(TransposeJob{c->w_bf16, c->wt_bf16, c->cout, c->r * c->s, c->cin, 0});
     }
@@ -366,10 +394,12 @@ int conv_wgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* 
     return launch_igemm_wgrad(st, a, net->G + c.w_off, 0);
 }
 
+// out_mask: ReLU mask of the block output this gradient belongs to (the masked gradient dz = dy * (y > 0) is what every block stores)
 int conv_dgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* dy, const uint16_t* residual, uint16_t* dx,
-               const uint8_t* residual_mask = nullptr) {
+               const uint8_t* out_mask = nullptr, const uint16_t* w_image = nullptr, const float* bias = nullptr) {
     IGemmArgs a{};
-    a.W = c.wt_bf16; a.X = dy; a.O = dx; a.Res = residual; a.res_mask = residual_mask; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.stats = nullptr;
+    a.W = w_image ? w_image : c.wt_bf16; a.X = dy; a.O = dx; a.Res = residual; a.out_mask = out_mask; a.bias = bias;
+    a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.stats = nullptr;
     a.Cm = c.cin; a.P = net->N * c.hin * c.win;
     a.g = conv_geom(c, 1);
     return launch_igemm_conv(st, a);
@@ -422,8 +452,31 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
         if ((rc = launch_bn_act(st, b.raw1, b.b1.scale, b.b1.shift, nullptr, nullptr, nullptr, nullptr, 1, e1, b.width, b.a1, nullptr))) return rc;
         if ((rc = conv_bn_fwd(net, st, b.c2, b.b2, b.a1, nullptr, b.raw2, tr))) return rc;
         if ((rc = launch_bn_act(st, b.raw2, b.b2.scale, b.b2.shift, nullptr, nullptr, nullptr, nullptr, 1, e2, b.width, b.a2, nullptr))) return rc;
-        if ((rc = conv_bn_fwd(net, st, b.c3, b.b3, b.a2, nullptr, b.raw3, tr))) return rc;
         const size_t elems = (size_t)net->N * b.hout * b.wout * b.cout;
+        if (b.lin3) {
+            // bn3's batch statistics from the moments of a2 (bnlin.hip), then conv3 writes y = relu(bn3(conv3(a2)) + x) and its ReLU mask itself
+            const int Pout = net->N * b.hout * b.wout;
+            if (tr) {
+                const Conv sq = square_conv(b.c3);
+                WGradArgs wa{};
+                wa.dY = b.a2; wa.X = b.a2; wa.partial = net->wgrad_slab; wa.Cm = b.width; wa.P = Pout; wa.Ntot = b.width;
+                wa.g = conv_geom(sq, 0);
+                size_t wsb;
+                wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
+                if ((rc = launch_igemm_wgrad(st, wa, b.gram, 0))) return rc;
+                if ((rc = launch_colsum(st, b.a2, Pout, b.width, b.m2, net->cs_partial, net->red_scratch))) return rc;
+                if ((rc = launch_bnlin_stats(st, b.c3.w_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
+                                             net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.b3.scale, b.b3.shift, b.b3.mean, b.b3.invstd))) return rc;
+            } else if ((rc = bn_eval(net, st, b.b3))) return rc;
+            IGemmArgs a{};
+            a.W = b.c3.w_bf16; a.X = b.a2; a.O = b.y; a.Res = x; a.out_scale = b.b3.scale; a.out_shift = b.b3.shift; a.out_relu = 1;
+            a.bits_out = tr ? b.ybits : nullptr;
+            a.Cm = b.cout; a.P = Pout; a.g = conv_geom(b.c3, 0);
+            if ((rc = launch_igemm_conv(st, a))) return rc;
+            x = b.y;
+            continue;
+        }
+        if ((rc = conv_bn_fwd(net, st, b.c3, b.b3, b.a2, nullptr, b.raw3, tr))) return rc;
         if (b.has_ds) {
             if ((rc = conv_bn_fwd(net, st, b.cd, b.bd, x, nullptr, b.rawd, tr))) return rc;
             rc = launch_bn_act(st, b.raw3, b.b3.scale, b.b3.shift, nullptr, b.rawd, b.bd.scale, b.bd.shift, 1, elems, b.cout, b.y, tr ? b.ybits : nullptr);
@@ -439,30 +492,44 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                            net->B + net->neck.rv_off, tr ? 1 : 0, 0.1f, 1e-5f, emb, net->neck_mean, net->neck_invstd);
 }
 
-// DALI_RESMASK=0 (A/B aid): the BatchNorm backward stores dz = dy * (y > 0) and conv1's data gradient adds it unmasked
-static bool res_mask_on() {
-    static int v = -1;
-    if (v == -1) { const char* e = getenv("DALI_RESMASK"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
-static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
+// Every block receives and hands on the MASKED gradient dz = dL/dy * (y > 0) (the gradient in front of the block's final ReLU): the
+// producer (the data-gradient epilogue of the next block's conv1, or the head pooling) applies the mask bits, so that neither the
+// BatchNorm backward nor the identity path has to.  prev_bits = ReLU mask of the previous block's output (null for the first block).
+static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint8_t* prev_bits) {
     int rc;
-    uint16_t* dy = net->cur_dy;                                   // grad wrt block output y
+    uint16_t* dz = net->cur_dy;                                   // masked grad wrt block output y
     const int Pout = net->N * b.hout * b.wout, Pin = net->N * b.hin * b.win;
-    uint16_t* d_raw3 = next_gbuf(net, dy);
-    uint16_t* d_rawd = b.has_ds ? next_gbuf(net, dy, d_raw3) : nullptr;
-    BnBwdSide s3{b.raw3, b.b3.mean, b.b3.invstd, b.b3.scale, b.b3.shift};
-    BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
-    // y = relu(bn3(raw3) + identity): dz = dy*(y>0) is not stored; the identity path's share is formed in conv1's data-gradient
-    // epilogue from dy and the block's 1-bit ReLU mask (one [P][cout] tensor write less per block without a downsample)
-    rc = launch_bn_bwd(st, dy, nullptr, b.ybits, s3, b.has_ds ? &sd : nullptr, 1, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
-                       net->G + b.b3.g_off, net->G + b.b3.b_off, b.has_ds ? net->G + b.bd.g_off : nullptr, b.has_ds ? net->G + b.bd.b_off : nullptr,
-                       d_raw3, d_rawd, (b.has_ds || res_mask_on()) ? nullptr : dy, net->red_scratch);
-    if (rc) return rc;
-    // conv3
-    if ((rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
-    uint16_t* d_a2 = next_gbuf(net, dy, d_raw3, d_rawd);
-    if ((rc = conv_dgrad(net, st, b.c3, d_raw3, nullptr, d_a2))) return rc;
+    uint16_t *d_a2, *d_rawd = nullptr, *scratch_a;
+    if (b.lin3) {
+        // bn3 + conv3 through the moments of a2 (bnlin.hip): no reduce / apply passes over [P][cout] tensors, raw3 does not exist
+        if ((rc = launch_colsum(st, dz, Pout, b.cout, b.sdz, net->cs_partial, net->red_scratch))) return rc;
+        WGradArgs wa{};
+        wa.dY = dz; wa.X = b.a2; wa.partial = net->wgrad_slab; wa.Cm = b.cout; wa.P = Pout; wa.Ntot = b.width;
+        wa.g = conv_geom(b.c3, 0);
+        size_t wsb;
+        wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
+        if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;                       // slabs of G0 = dz^T a2
+        if ((rc = launch_bnlin_bwd(st, net->wgrad_slab, wa.splits, b.c3.w_bf16, b.gram, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
+                                   b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.c3.wt_bf16, b.wd2, b.bvec, b.qk))) return rc;
+        d_a2 = next_gbuf(net, dz);
+        scratch_a = next_gbuf(net, dz, d_a2);
+        if ((rc = conv_dgrad(net, st, b.c3, dz, nullptr, d_a2, nullptr, b.c3.wt_bf16, b.bvec))) return rc;      // dz (A.W3) + W3^T Kc
+        const Conv sq = square_conv(b.c3);
+        if ((rc = conv_dgrad(net, st, sq, b.a2, d_a2, d_a2, nullptr, b.wd2, nullptr))) return rc;               // - a2 (W3^T diag(Q) W3), in place
+    } else {
+        uint16_t* d_raw3 = next_gbuf(net, dz);
+        d_rawd = b.has_ds ? next_gbuf(net, dz, d_raw3) : nullptr;
+        BnBwdSide s3{b.raw3, b.b3.mean, b.b3.invstd, b.b3.scale, b.b3.shift};
+        BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
+        rc = launch_bn_bwd(st, dz, nullptr, nullptr, s3, b.has_ds ? &sd : nullptr, 0, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
+                           net->G + b.b3.g_off, net->G + b.b3.b_off, b.has_ds ? net->G + b.bd.g_off : nullptr, b.has_ds ? net->G + b.bd.b_off : nullptr,
+                           d_raw3, d_rawd, nullptr, net->red_scratch);
+        if (rc) return rc;
+        if ((rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
+        d_a2 = next_gbuf(net, dz, d_raw3, d_rawd);
+        if ((rc = conv_dgrad(net, st, b.c3, d_raw3, nullptr, d_a2))) return rc;
+        scratch_a = d_raw3;                                       // d_raw3 is dead from here on
+    }
     // bn2 + relu, in place.  The ReLU mask is recomputed from raw2 (raw*scale+shift > 0 <=> a2 > 0: bf16 rounding cannot
     // flush a positive fp32 to zero) instead of reading a2: one tensor read less in each of the two passes.
     BnBwdSide s2{b.raw2, b.b2.mean, b.b2.invstd, b.b2.scale, b.b2.shift};
@@ -470,22 +537,23 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b) {
                             net->G + b.b2.b_off, nullptr, nullptr, d_a2, nullptr, nullptr, net->red_scratch))) return rc;
     // conv2
     if ((rc = conv_wgrad(net, st, b.c2, b.a1, nullptr, d_a2))) return rc;
-    uint16_t* d_a1 = d_raw3;                                      // d_raw3 is dead now
+    uint16_t* d_a1 = scratch_a;
     if ((rc = conv_dgrad(net, st, b.c2, d_a2, nullptr, d_a1))) return rc;
     BnBwdSide s1{b.raw1, b.b1.mean, b.b1.invstd, b.b1.scale, b.b1.shift};
     if ((rc = launch_bn_bwd(st, d_a1, nullptr, nullptr, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
                             net->G + b.b1.b_off, nullptr, nullptr, d_a1, nullptr, nullptr, net->red_scratch))) return rc;
-    // conv1 (+ identity / downsample branch)
+    // conv1 (+ identity / downsample branch); the result is masked with the previous block's ReLU bits
     if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
     uint16_t* dx = d_a2;                                          // d_a2 is dead now
     if (b.has_ds) {
         if ((rc = conv_wgrad(net, st, b.cd, b.x, nullptr, d_rawd))) return rc;
         // conv1's data gradient first, then the downsample branch accumulates into it in place: with stride 2 only the
-        // even-even quarter of the positions receives a contribution (launch_igemm_conv's parity split)
-        if ((rc = conv_dgrad(net, st, b.c1, d_a1, nullptr, dx))) return rc;
-        if ((rc = conv_dgrad(net, st, b.cd, d_rawd, dx, dx))) return rc;
+        // even-even quarter of the positions receives a contribution (launch_igemm_conv's parity split).  (a + b) * m = a * m + b * m:
+        // both launches apply the mask.
+        if ((rc = conv_dgrad(net, st, b.c1, d_a1, nullptr, dx, prev_bits))) return rc;
+        if ((rc = conv_dgrad(net, st, b.cd, d_rawd, dx, dx, prev_bits))) return rc;
     } else {
-        if ((rc = conv_dgrad(net, st, b.c1, d_a1, dy, dx, res_mask_on() ? b.ybits : nullptr))) return rc;
+        if ((rc = conv_dgrad(net, st, b.c1, d_a1, dz, dx, prev_bits))) return rc;             // identity path: + dz
     }
     net->cur_dy = dx;
     net->cur_dy_bytes = (int64_t)Pin * b.cin * 2;
@@ -507,11 +575,12 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
             if ((rc = launch_bn1d_bwd(st, net->feat, d_emb, net->N, net->feat_dim, net->P + net->neck.g_off, net->neck_mean, net->neck_invstd,
                                       net->dfeat, net->G + net->neck.g_off, net->G + net->neck.b_off))) return rc;
             net->cur_dy = net->gbuf[0];
-            if ((rc = launch_head_pool_bwd(st, net->dfeat, net->head_arg, net->N, net->head_hw, net->feat_dim, net->feature_mode, net->cur_dy))) return rc;
+            if ((rc = launch_head_pool_bwd(st, net->dfeat, net->head_arg, net->N, net->head_hw, net->feat_dim, net->feature_mode, net->cur_dy,
+                                           net->blocks.back().ybits))) return rc;
             net->cur_dy_bytes = (int64_t)net->N * net->head_hw * net->feat_dim * 2;
         }
         for (int bi = net->stage_last[li]; bi >= net->stage_first[li]; --bi)
-            if ((rc = block_backward(net, st, net->blocks[bi]))) return rc;
+            if ((rc = block_backward(net, st, net->blocks[bi], bi > 0 ? net->blocks[bi - 1].ybits : nullptr))) return rc;
         if (stage == 3) {
             // maxpool + stem BN backward, then the stem weight gradient (no data gradient: images need none)
             uint16_t* d_raw0 = next_gbuf(net, net->cur_dy);
@@ -558,7 +627,7 @@ extern "C" int dali_resnet_debug_tensor(dali_resnet* net, const char* name, void
                 const size_t pin = N * b.hin * b.win, pout = N * b.hout * b.wout;
                 if (f == "raw1") { *ptr = b.raw1; *bytes = (int64_t)(pin * b.width * 2); return DALI_OK; }
                 if (f == "raw2") { *ptr = b.raw2; *bytes = (int64_t)(pout * b.width * 2); return DALI_OK; }
-                if (f == "raw3") { *ptr = b.raw3; *bytes = (int64_t)(pout * b.cout * 2); return DALI_OK; }
+                if (f == "raw3" && !b.lin3) { *ptr = b.raw3; *bytes = (int64_t)(pout * b.cout * 2); return DALI_OK; }
                 if (f == "rawd" && b.has_ds) { *ptr = b.rawd; *bytes = (int64_t)(pout * b.cout * 2); return DALI_OK; }
                 if (f == "y") { *ptr = b.y; *bytes = (int64_t)(pout * b.cout * 2); return DALI_OK; }
                 if (f.rfind("bn", 0) == 0 && f.size() > 4) {

@@ -61,6 +61,45 @@ def conv2d_wgrad(x, dy, rs, stride=1, pad=0, in_scale=None, in_shift=None, in_re
     return out
 
 
+def conv1x1_fused(x, w, out_scale=None, out_shift=None, bias=None, residual=None, relu=False, want_bits=False, out_mask=None, inplace=False):
+    """x [P,cin] bf16, w [cout,cin] bf16 -> y [P,cout] = gate(relu?(acc*scale + shift + bias + residual)) (, bits uint8 [P*cout/8])."""
+    P, cin = x.shape
+    cout = w.shape[0]
+    y = residual if inplace else torch.empty(P, cout, device=x.device, dtype=bf16)
+    bits = torch.empty(P * cout // 8, device=x.device, dtype=torch.uint8) if want_bits else None
+    _lib.check(_lib.lib().dali_conv1x1_fused(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16, "x"), _lib.ptr(w, bf16, "w"), _lib.ptr(y),
+                                              P, cin, cout, _lib.ptr(out_scale), _lib.ptr(out_shift), _lib.ptr(bias), _lib.ptr(residual), int(relu),
+                                              _lib.ptr(bits), _lib.ptr(out_mask, torch.uint8, "out_mask")), "dali_conv1x1_fused")
+    return (y, bits) if want_bits else y
+
+
+def bnlin_fwd(a, w, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """a [P,w] bf16, w [C,w] bf16 -> dict(gram, m2, scale, shift, mean, invstd): training-mode BatchNorm coefficients of a @ w.T"""
+    P, wd = a.shape
+    C = w.shape[0]
+    dev = a.device
+    o = dict(gram=torch.empty(wd, wd, device=dev), m2=_f32(wd, dev), scale=_f32(C, dev), shift=_f32(C, dev), mean=_f32(C, dev), invstd=_f32(C, dev))
+    _lib.check(_lib.lib().dali_bnlin_fwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(a, bf16, "a"), _lib.ptr(w, bf16, "w"), P, C, wd, _lib.ptr(gamma),
+                                          _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var), momentum, eps, _lib.ptr(o["gram"]),
+                                          _lib.ptr(o["m2"]), _lib.ptr(o["scale"]), _lib.ptr(o["shift"]), _lib.ptr(o["mean"]), _lib.ptr(o["invstd"])),
+               "dali_bnlin_fwd")
+    return o
+
+
+def bnlin_bwd(dz, a, w, fwd):
+    """-> dict(dW [C,w], dgamma, dbeta, wd1 [w,C] bf16, wd2 [w,w] bf16, bvec [w]); fwd = the dict bnlin_fwd returned"""
+    P, wd = a.shape
+    C = w.shape[0]
+    dev = a.device
+    o = dict(dW=torch.empty(C, wd, device=dev), dgamma=_f32(C, dev), dbeta=_f32(C, dev), wd1=torch.empty(wd, C, device=dev, dtype=bf16),
+             wd2=torch.empty(wd, wd, device=dev, dtype=bf16), bvec=_f32(wd, dev))
+    _lib.check(_lib.lib().dali_bnlin_bwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(dz, bf16, "dz"), _lib.ptr(a, bf16, "a"), _lib.ptr(w, bf16, "w"), P, C, wd,
+                                          _lib.ptr(fwd["gram"]), _lib.ptr(fwd["m2"]), _lib.ptr(fwd["scale"]), _lib.ptr(fwd["mean"]), _lib.ptr(fwd["invstd"]),
+                                          _lib.ptr(o["dW"]), _lib.ptr(o["dgamma"]), _lib.ptr(o["dbeta"]), _lib.ptr(o["wd1"]), _lib.ptr(o["wd2"]),
+                                          _lib.ptr(o["bvec"])), "dali_bnlin_bwd")
+    return o
+
+
 # ---- BatchNorm / pooling / head single ops -------------------------------------------------------------------
 def _f32(n, dev):
     return torch.empty(n, device=dev, dtype=torch.float32)

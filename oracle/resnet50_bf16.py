@@ -9,7 +9,8 @@ that drift says nothing about correctness.  This twin rounds where the kernels r
 summation order -- and any real indexing / fusion bug.
 
 Rounding points mirrored (daliid_amd/csrc/resnet_plan.hip):
-  images and conv weights -> bf16 operands; every raw conv output stored bf16; relu(bn(raw)) rounded to bf16 when
+  images and conv weights -> bf16 operands; every raw conv output stored bf16 (except conv3 of the blocks without a downsample
+  branch, whose BatchNorm is applied to the fp32 accumulators inside the GEMM: csrc/bnlin.hip); relu(bn(raw)) rounded to bf16 when
   it is formed in the consumer's operand load; block outputs y and the pooled stem output stored bf16; in the
   backward pass the gradients of those same tensors are stored bf16.  BatchNorm statistics come from the fp32
   accumulators (the un-rounded conv result) and are applied to the rounded tensor; weight gradients stay fp32.
@@ -74,7 +75,8 @@ def forward_matched(model, x):
             u2 = _conv(a1, blk.conv2)
             a2 = Q(F.relu(_bn_train(u2, Q(u2), blk.bn2)))
             u3 = _conv(a2, blk.conv3)
-            out = _bn_train(u3, Q(u3), blk.bn3)
+            # blocks without a downsample branch: conv3's output is never stored (csrc/bnlin.hip), bn3 acts on the fp32 accumulators
+            out = _bn_train(u3, Q(u3) if blk.downsample is not None else u3, blk.bn3)
             if blk.downsample is not None:
                 ud = _conv(x, blk.downsample[0])
                 idn = _bn_train(ud, Q(ud), blk.downsample[1])
