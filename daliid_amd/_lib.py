@@ -154,6 +154,11 @@ def ctx(device=None):
     device = torch.device(device).index if not isinstance(device, int) else device
     if device is None:
         device = torch.cuda.current_device()
+    if device != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's stream and the per-device kernel attributes are set for it: a tensor that
+        # lives elsewhere must be handled under `with torch.cuda.device(...)`
+        raise DaliError("tensors live on cuda:%d but the current device is cuda:%d; wrap the call in torch.cuda.device(%d)"
+                        % (device, torch.cuda.current_device(), device))
     c = _ctxs.get(device)
     if c is None:
         with _lock:

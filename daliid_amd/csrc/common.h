@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 #include "../../include/daliid.h"
 
 namespace dali {
@@ -42,6 +43,28 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
     } while (0)
 
 #define DALI_LAUNCH_CHECK() DALI_HIP(hipGetLastError())
+
+namespace dali {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: the opt-in blocks run once per device (of the calling
+// thread's current device), under a lock, and are retried if they failed.
+struct DeviceOnce {
+    std::mutex mu;
+    unsigned long long done_mask = 0;
+    struct Guard {
+        DeviceOnce& o; unsigned long long bit = 1;
+        explicit Guard(DeviceOnce& once) : o(once) { o.mu.lock(); int dev = 0; if (hipGetDevice(&dev) == hipSuccess) bit = 1ull << (dev & 63); }
+        ~Guard() { o.mu.unlock(); }
+        bool first() const { return !(o.done_mask & bit); }
+        void done() { o.done_mask |= bit; }
+    };
+};
+}  // namespace dali
+#define DALI_ONCE_PER_DEVICE(...)                         \
+    do {                                                  \
+        static dali::DeviceOnce once_;                    \
+        dali::DeviceOnce::Guard guard_(once_);            \
+        if (guard_.first()) { __VA_ARGS__; guard_.done(); } \
+    } while (0)
 
 // ---- device helpers -------------------------------------------------------------------------
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

@@ -1999,12 +1999,10 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             set_error("conv: the fused output stage needs Cm %% 8 == 0, tensors below 2 GiB, no operand transform and no linear-layer extras");
             return DALI_ERR_INVALID;
         }
-        static bool attr_set = false;
-        if (!attr_set) {
+        DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 256) * 64 * 2 * 2));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 256) * 32 * 2 * 3));
-            attr_set = true;
-        }
+        });
         if (k64 && cfg == CONV_256x256) {
             const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
             hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
@@ -2017,50 +2015,43 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         }
     } else if (k64 && cfg == CONV_256x256) {
-        static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
         const int lds = (256 + 256) * 64 * 2 * 2;
         // (8 waves with 128 x 64 per wave, 25 % fewer LDS fragment bytes, 192 VGPRs: measured 3-5 % slower than 16 waves of 64 x 64)
         // and the wave-specialised form (8 consumers of 128 x 64 + 4 producers, 168 VGPRs, 2-stage ring): -2 % on layer4's 3x3, +14 % on
         // the stride-2 downsample dgrad -- a 256 x 256 tile has no room for producers beside 16 consumers (1024 threads per workgroup)
-        if (!attr_set) {
+        DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+        });
         if (lin) hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128x256) {
-        static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
         const int lds = (128 + 256) * 64 * 2 * 3;
-        if (!attr_set) {
+        DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+        });
         if (k64 == 6) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
         else if (lin) hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128) {
-        static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
-        if (!attr_set) {
+        DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 2 * 2));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 2 * 3));
-            attr_set = true;
-        }
+        });
         if (k64 == 3) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 2, st, args, tiles_m, tiles_n);
     } else if (narrow_k64 == 2) {
         // layer1's 3x3 (Cm = Cin = 64, K = 576): k-tile 64 = one full line per pixel and tap, 4 MFMA waves + 4 DMA waves, 2-stage ring,
         // two workgroups per CU: 94 -> 77 us forward, 90 -> 73 us data gradient (unspecialised k-tile 64: 84 / 79; 3-stage ring, one
         // workgroup per CU: 122 / 118)
-        static bool attr_set = false;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
         const int lds = (64 + 256) * 64 * 2 * 2;
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
         hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
@@ -2070,26 +2061,22 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<64, 256, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
     } else if (!in_bn && dma_ok && cfg == CONV_256x256) {
-        static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
         const int lds = (256 + 256) * 32 * 2 * 4;
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
         hipLaunchKernelGGL((igemm_conv_wg_kernel<4, 4, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (!in_bn && dma_ok && cfg == CONV_256x128) {
-        static bool attr_set = false;
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 127) / 128;
         const int lds = (256 + 128) * 32 * 2 * 3;
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
         hipLaunchKernelGGL((igemm_conv_wg_kernel<4, 2, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else if (!in_bn && dma_ok && cfg == CONV_128x256) {
-        static bool attr_set = false;
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
         const int lds = (128 + 256) * 32 * 2 * 3;
-        if (!attr_set) {
+        DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+        });
         if (lin) hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else {
@@ -2174,27 +2161,23 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
                          a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck;
     const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P, halo_ok ? a.g.Wout : 0);
     if (!a.in_scale && dma_ok && wcfg == 3) {
-        static bool attr_set = false;
         const int tm3 = (a.Cm + 127) / 128, tn3 = a.g.Ck / 64;
         const int lds = 3 * W3_STAGE * 2;            // 3 stages x 24 KiB (4 and 5 measured the same, before and after the inline-asm reads: the
                                                      // k-step is bound by its 26 transposing reads + 36 MFMAs per wave, two waves per SIMD)
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
         hipLaunchKernelGGL(igemm_wgrad3x3_kernel<3>, dim3(((tm3 * tn3 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm3, tn3);
     } else if (!a.in_scale && dma_ok && wcfg == 1) {
-        static bool attr_set = false;
         const int tm2 = (a.Cm + 255) / 256, tn2 = (a.Ntot + 255) / 256;
         const int lds = 4 * 4 * 32 * 128 * 2;       // 4 stages x 4 images x 8 KiB
-        if (!attr_set) { DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set = true; }
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
         hipLaunchKernelGGL((igemm_wgrad_wg_kernel<4, 4, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds, st, args, tm2, tn2);
     } else if (!a.in_scale && dma_ok && wcfg == 2) {
-        static bool attr_set = false;
         const int tm2 = (a.Cm + 127) / 128, tn2 = (a.Ntot + 255) / 256;
         const int lds = 3 * 3 * 32 * 128 * 2;       // 3 stages x 3 images x 8 KiB
-        if (!attr_set) {
+        DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
-            attr_set = true;
-        }
+        });
         if (wgrad_spec(a.Cm, a.Ntot)) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
         else hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm2, tn2);
     } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);

@@ -43,9 +43,8 @@ extern "C" int dali_ctx_create(int device, dali_ctx** out) {
     int ndev = 0;
     DALI_HIP(hipGetDeviceCount(&ndev));
     DALI_REQUIRE(device >= 0 && device < ndev, "dali_ctx_create: device %d not in [0,%d)", device, ndev);
-    DALI_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
-    DALI_HIP(hipGetDeviceProperties(&prop, device));
+    DALI_HIP(hipGetDeviceProperties(&prop, device));          // (no hipSetDevice: the caller's current device is left alone)
     if (std::string_view(prop.gcnArchName).substr(0, 6) != "gfx950") {
         dali::set_error("dali_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return DALI_ERR_UNSUPPORTED;

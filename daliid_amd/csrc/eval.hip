@@ -610,12 +610,10 @@ static int launch_pairdist(int num_cus, hipStream_t st, const uint16_t* g_img, c
         const int tm2 = (ng + 127) / 128, tn2 = (nq + 255) / 256;
         const int grid2 = xcd_tile_grid(tm2, tn2);
         const int lds = 3 * (128 + 256) * 64 * 2;                                // 3 stages x 48 KiB
-        static bool attr_set = false;
-        if (!attr_set) {
+        DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+        });
         const int cap = num_cus / 8 * 8, grid = grid2 < cap ? grid2 : cap;          // persistent: one workgroup per CU (144 KiB of LDS each)
         if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 32, metric, out, tm2, tn2, grid2, blend);
         else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, Kp / 64, metric, out, tm2, tn2, grid2, blend);
