@@ -21,7 +21,7 @@
 namespace dali {
 
 namespace {
-constexpr int BL_CH = 8;          // channels per workgroup of the stats / row kernels
+constexpr int BL_CH = 8;          // channels per workgroup of the row kernel
 
 __device__ __forceinline__ double block_sum_d(double v, double* red) {       // 256 threads; result in every thread
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -32,78 +32,152 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {       // 
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
+__device__ __forceinline__ float ld_f(const float* p) { return *p; }
+__device__ __forceinline__ float ld_f(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+}  // namespace
 
-// wf[ch][k] (LDS, fp32) <- bf16 rows c0 .. c0+BL_CH-1 of W [C][w]
-__device__ __forceinline__ void load_w_rows(const uint16_t* __restrict__ W, int c0, int C, int w, float* wf) {
-    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {
-        const int ch = e / w, k = e - ch * w;
-        wf[e] = (c0 + ch < C) ? bf16_bits_to_f32(W[(size_t)(c0 + ch) * w + k]) : 0.f;
+// ------------------------------------------------------------------------------------------------
+// The two small products of the scheme, W G ([C][w] x [w][w]) and W^T diag(Q) W ([w][C] x [C][w]): 0.5 GMAC each at layer4, exact fp32
+// wanted (they carry batch statistics and BatchNorm's mean corrections).  v_mfma_f32_32x32x2_f32 = an fp32 fmaf chain at the fp32
+// vector peak without any VALU work.  "TN" form, both operands k-major so that every load is a coalesced row piece:
+//     C[m][n] = sum_k sa[k] * A[k][m] * B[k][n]          A [K][lda] (fp32 or bf16), B [K][ldb] bf16, sa optional [K]
+// One workgroup = one 32 x 32 output tile; its 4 waves split K four ways (k = 8*(4*it + wave) + ...) and are summed through LDS in a
+// fixed order: no split-K slabs, 256 tiles x 4 waves fill the chip at w = 512.  Lane (i = lane & 31, h = lane >> 5) feeds MFMA t of an
+// 8-deep k-step with k = k8 + 2t + h (any k order works as long as A and B agree).
+// Epilogues: C as fp32 [M][ldc]; or bf16 of -C; optionally dot[m-tile][n] = sum_{m in tile} C[m][n] * B2[m][n] (the quadratic form
+// w_c G w_c^T per output channel) and vsum[n] = sum_k v[k] B[k][n] on the m-tile-0 workgroups (W^T Kc).
+// ------------------------------------------------------------------------------------------------
+template <class TA, bool HAS_SA, bool HAS_V>
+__global__ __launch_bounds__(256) void bnlin_tn_gemm_kernel(const TA* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, const float* __restrict__ sa,
+                                                             int K, float* __restrict__ Cf, uint16_t* __restrict__ Cneg, int ldc,
+                                                             const uint16_t* __restrict__ B2, int ldb2, float* __restrict__ dot, int ldd,
+                                                             const float* __restrict__ v, float* __restrict__ vsum) {
+    __shared__ float red[3][16][64];                    // partial accumulators of waves 1..3
+    __shared__ float vred[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float vs = 0.f;
+    const bool do_v = HAS_V && blockIdx.y == 0;
+    const TA* ap = A + m0 + i;
+    const uint16_t* bp = B + n0 + i;
+    // K is a multiple of 32: every wave runs K / 32 steps of 8 k.  Two steps of loads (16 values) are in flight ahead of the MFMAs.
+    struct Step { float a[4], b[4], s[4], vv[4]; };
+    auto load = [&](int k8, Step& st) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k8 + 2 * t + h;
+            st.a[t] = ld_f(ap + (size_t)k * lda);
+            st.b[t] = bf16_bits_to_f32(bp[(size_t)k * ldb]);
+            st.s[t] = HAS_SA ? sa[k] : 1.f;
+            st.vv[t] = HAS_V ? v[k] : 0.f;
+        }
+    };
+    auto fma = [&](const Step& st) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float a = HAS_SA ? st.a[t] * st.s[t] : st.a[t];
+            if (HAS_V) vs += st.vv[t] * st.b[t];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st.b[t], acc, 0, 0, 0);
+        }
+    };
+    Step s0, s1;
+    int k8 = wave * 8;
+    load(k8, s0);
+    if (k8 + 32 < K) load(k8 + 32, s1);
+    for (; k8 + 64 < K; k8 += 64) {
+        Step s2, s3;
+        load(k8 + 64, s2);
+        if (k8 + 96 < K) load(k8 + 96, s3); else s3 = s2;
+        fma(s0); fma(s1);
+        s0 = s2; s1 = s3;
     }
-}
-
-// u[ch] = sum_k wf[ch][k] * gram[k][kp] for this thread's column kp (gram rows are read coalesced across the threads' columns)
-__device__ __forceinline__ void gram_column(const float* __restrict__ gram, const float* wf, int w, int kp, float (&u)[BL_CH]) {
+    fma(s0);
+    if (k8 + 32 < K) fma(s1);
+    if (!do_v) vs = 0.f;
+    // C/D layout: column n = n0 + i, row m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h
+    if (wave > 0) {
 #pragma unroll
-    for (int ch = 0; ch < BL_CH; ++ch) u[ch] = 0.f;
-    for (int k = 0; k < w; k += 4) {
-        const float g0 = gram[(size_t)k * w + kp], g1 = gram[(size_t)(k + 1) * w + kp], g2 = gram[(size_t)(k + 2) * w + kp], g3 = gram[(size_t)(k + 3) * w + kp];
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    vred[wave][lane] = vs;
+    __syncthreads();
+    if (wave == 0) {
 #pragma unroll
-        for (int ch = 0; ch < BL_CH; ++ch) {
-            const float4 wv = *reinterpret_cast<const float4*>(wf + ch * w + k);
-            u[ch] += wv.x * g0 + wv.y * g1 + wv.z * g2 + wv.w * g3;
+        for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + i;
+            if (Cf) Cf[(size_t)m * ldc + n] = acc[r];
+            if (Cneg) Cneg[(size_t)m * ldc + n] = f32_to_bf16_bits(-acc[r]);
+            if (B2) d += acc[r] * bf16_bits_to_f32(B2[(size_t)m * ldb2 + n]);
+        }
+        if (B2) {
+            d += __shfl_xor(d, 32, 64);                 // the two row halves of the tile
+            if (h == 0) dot[(size_t)blockIdx.y * ldd + n0 + i] = d;
+        }
+        if (do_v) {
+            float t = ((vred[0][lane] + vred[1][lane]) + vred[2][lane]) + vred[3][lane];
+            t += __shfl_xor(t, 32, 64);
+            if (h == 0) vsum[n0 + i] = t;
         }
     }
 }
-}  // namespace
 
-// ---- forward: batch statistics of raw3 = a2 W^T from the moments of a2 -> scale / shift / mean / invstd (+ running statistics) ----
-__global__ __launch_bounds__(256) void bnlin_stats_kernel(const uint16_t* __restrict__ W, const float* __restrict__ gram, const float* __restrict__ m2,
-                                                           int C, int w, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                                                           float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
-                                                           float* __restrict__ invstd_out) {
-    extern __shared__ __attribute__((aligned(16))) float bl_smem[];
-    float* wf = bl_smem;                                    // [BL_CH][w]
-    __shared__ double red[4];
-    const int c0 = blockIdx.x * BL_CH;
-    load_w_rows(W, c0, C, w, wf);
-    __syncthreads();
-    double q[BL_CH], mu[BL_CH];
+// ---- forward: scale / shift / mean / invstd (+ running statistics) from the per-tile quadratic-form partials and W^T m2 ----
+//     E[raw^2][c] = sum_tiles dot[tile][c] / P,   mean[c] = sum_k m2[k] W^T[k][c] / P        (block = 64 channels x 4 k groups)
+__global__ __launch_bounds__(256) void bnlin_finish_kernel(const float* __restrict__ dot, int tiles, const uint16_t* __restrict__ Wt, const float* __restrict__ m2,
+                                                            int C, int w, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                                            float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out) {
+    __shared__ double red[2][4][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double mu = 0.0, q = 0.0;
+    if (c < C) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = grp;
+        for (; k + 12 < w; k += 16) {
+            float wv[4], mv[4];
 #pragma unroll
-    for (int ch = 0; ch < BL_CH; ++ch) { q[ch] = 0.0; mu[ch] = 0.0; }
-    for (int kp = threadIdx.x; kp < w; kp += 256) {
-        float u[BL_CH];
-        gram_column(gram, wf, w, kp, u);
-        const float m = m2[kp];
+            for (int u = 0; u < 4; ++u) { wv[u] = bf16_bits_to_f32(Wt[(size_t)(k + 4 * u) * C + c]); mv[u] = m2[k + 4 * u]; }
 #pragma unroll
-        for (int ch = 0; ch < BL_CH; ++ch) { const float wk = wf[ch * w + kp]; q[ch] += (double)u[ch] * (double)wk; mu[ch] += (double)wk * (double)m; }
+            for (int u = 0; u < 4; ++u) part[u] += (double)wv[u] * (double)mv[u];
+        }
+        for (; k < w; k += 4) part[0] += (double)bf16_bits_to_f32(Wt[(size_t)k * C + c]) * (double)m2[k];
+        mu = (part[0] + part[1]) + (part[2] + part[3]);
+        for (int t = grp; t < tiles; t += 4) q += (double)dot[(size_t)t * C + c];
     }
-#pragma unroll
-    for (int ch = 0; ch < BL_CH; ++ch) {
-        const double qs = block_sum_d(q[ch], red), ms = block_sum_d(mu[ch], red);
-        const int c = c0 + ch;
-        if (threadIdx.x == 0 && c < C) {
-            const double mean = ms / count;
-            double var = qs / count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float sc = gamma[c] * invstd;
-            scale[c] = sc;
-            shift[c] = beta[c] - (float)mean * sc;
-            mean_out[c] = (float)mean;
-            invstd_out[c] = invstd;
-            if (running_mean) {                              // torch's update rule, as bn_finalize_kernel (nnops.hip)
-                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-            }
+    red[0][grp][cx] = mu; red[1][grp][cx] = q;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        mu = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+        q = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+        const double mean = mu / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        if (running_mean) {                              // torch's update rule, as bn_finalize_kernel (nnops.hip)
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
     }
 }
 
 // ---- backward, per group of BL_CH output channels: split-K slabs of G0 = dz^T a2 -> dgamma, dbeta, folded coefficients, dW, A.W ----
+// Ut = (W G)^T [w][C] was left by the forward's TN product.
 __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict__ slabs, int splits, const uint16_t* __restrict__ W,
-                                                         const float* __restrict__ gram, const float* __restrict__ m2, const float* __restrict__ s_dz,
+                                                         const float* __restrict__ Ut, const float* __restrict__ m2, const float* __restrict__ s_dz,
                                                          int C, int w, double count, const float* __restrict__ scale, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float* __restrict__ dW, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, uint16_t* __restrict__ wd1, float* __restrict__ qk) {
@@ -112,22 +186,19 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict_
     float* g0 = wf + BL_CH * w;                             // [BL_CH][w]
     __shared__ double red[4];
     __shared__ float coef[BL_CH][3];                        // A, Kc, Q
-    const int c0 = blockIdx.x * BL_CH;
-    load_w_rows(W, c0, C, w, wf);
+    const int c0 = blockIdx.x * BL_CH;                      // C % BL_CH == 0 (checked by the launcher)
     const size_t slab = (size_t)C * w;
-    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // fixed-order sum over the split-K slabs (deterministic)
-        const int ch = e / w;
+    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // fixed-order sum over the split-K slabs (deterministic), 4 loads in flight
+        const float* p = slabs + (size_t)c0 * w + e;
         float acc = 0.f;
-        if (c0 + ch < C) {
-            const float* p = slabs + (size_t)c0 * w + e;
-            int sidx = 0;
-            for (; sidx + 4 <= splits; sidx += 4) {
-                const float v0 = p[(size_t)sidx * slab], v1 = p[(size_t)(sidx + 1) * slab], v2 = p[(size_t)(sidx + 2) * slab], v3 = p[(size_t)(sidx + 3) * slab];
-                acc += v0; acc += v1; acc += v2; acc += v3;
-            }
-            for (; sidx < splits; ++sidx) acc += p[(size_t)sidx * slab];
+        int sidx = 0;
+        for (; sidx + 4 <= splits; sidx += 4) {
+            const float v0 = p[(size_t)sidx * slab], v1 = p[(size_t)(sidx + 1) * slab], v2 = p[(size_t)(sidx + 2) * slab], v3 = p[(size_t)(sidx + 3) * slab];
+            acc += v0; acc += v1; acc += v2; acc += v3;
         }
+        for (; sidx < splits; ++sidx) acc += p[(size_t)sidx * slab];
         g0[e] = acc;
+        wf[e] = bf16_bits_to_f32(W[(size_t)c0 * w + e]);
     }
     __syncthreads();
 #pragma unroll
@@ -137,98 +208,56 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict_
         t = block_sum_d(t, red);
         const int c = c0 + ch;
         if (threadIdx.x == 0) {
-            float A = 0.f, Kc = 0.f, Q = 0.f;
-            if (c < C) {
-                const double s = (double)s_dz[c], iv = (double)invstd[c], mn = (double)mean[c], a = (double)scale[c];
-                const double dg = iv * (t - mn * s);                    // sum dz * xhat
-                const double qq = a * iv * dg / count;
-                A = (float)a; Q = (float)qq; Kc = (float)(qq * mn - a * s / count);
-                dgamma[c] = (float)dg;
-                dbeta[c] = (float)s;
-                qk[c] = Q; qk[C + c] = Kc;
-            }
-            coef[ch][0] = A; coef[ch][1] = Kc; coef[ch][2] = Q;
+            const double s = (double)s_dz[c], iv = (double)invstd[c], mn = (double)mean[c], a = (double)scale[c];
+            const double dg = iv * (t - mn * s);                    // sum dz * xhat
+            const double qq = a * iv * dg / count;
+            dgamma[c] = (float)dg;
+            dbeta[c] = (float)s;
+            qk[c] = (float)qq; qk[C + c] = (float)(qq * mn - a * s / count);
+            coef[ch][0] = (float)a; coef[ch][1] = (float)(qq * mn - a * s / count); coef[ch][2] = (float)qq;
         }
     }
     __syncthreads();
-    for (int kp = threadIdx.x; kp < w; kp += 256) {         // dW[c][kp] = A G0 + Kc m2 - Q (W G)
-        float u[BL_CH];
-        gram_column(gram, wf, w, kp, u);
-        const float m = m2[kp];
+    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // dW[c][k] = A G0 + Kc m2 - Q (W G)   (thread -> (k, ch): 32-byte pieces of Ut rows)
+        const int k = e / BL_CH, ch = e - k * BL_CH;
+        const float u = Ut[(size_t)k * C + c0 + ch];
+        dW[(size_t)(c0 + ch) * w + k] = coef[ch][0] * g0[ch * w + k] + coef[ch][1] * m2[k] - coef[ch][2] * u;
+    }
+    for (int k = threadIdx.x; k < w; k += 256) {            // A.W, transposed into the data-gradient image [w][C]: 8 channels = 16 bytes per k
+        uint32_t o[4];
 #pragma unroll
-        for (int ch = 0; ch < BL_CH; ++ch)
-            if (c0 + ch < C) dW[(size_t)(c0 + ch) * w + kp] = coef[ch][0] * g0[ch * w + kp] + coef[ch][1] * m - coef[ch][2] * u[ch];
+        for (int t = 0; t < 4; ++t) o[t] = pack_bf16x2(coef[2 * t][0] * wf[(2 * t) * w + k], coef[2 * t + 1][0] * wf[(2 * t + 1) * w + k]);
+        *reinterpret_cast<uint4*>(wd1 + (size_t)k * C + c0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    if (c0 + BL_CH <= C) {                                  // A.W, transposed into the data-gradient image [w][C]: 8 channels = 16 bytes per k
-        for (int k = threadIdx.x; k < w; k += 256) {
-            uint32_t o[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] = pack_bf16x2(coef[2 * t][0] * wf[(2 * t) * w + k], coef[2 * t + 1][0] * wf[(2 * t + 1) * w + k]);
-            *reinterpret_cast<uint4*>(wd1 + (size_t)k * C + c0) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-    } else {
-        for (int e = threadIdx.x; e < BL_CH * w; e += 256) {
-            const int ch = e / w, k = e - ch * w;
-            if (c0 + ch < C) wd1[(size_t)k * C + c0 + ch] = f32_to_bf16_bits(coef[ch][0] * wf[e]);
-        }
-    }
-}
-
-// ---- backward: -M = -(W^T diag(Q) W) as the second data-gradient weight image [w][w] (bf16) and bvec = W^T Kc ----
-__global__ __launch_bounds__(256) void bnlin_m_kernel(const uint16_t* __restrict__ W, const float* __restrict__ qk, int C, int w,
-                                                       uint16_t* __restrict__ wd2, float* __restrict__ bvec) {
-    __shared__ float sa[32][33], sb[32][33], sq[32], sk[32];
-    const int ti = blockIdx.y * 32, tj = blockIdx.x * 32;           // rows k (ti), columns k' (tj) of M
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // thread -> outputs (2*ty + {0,1}, 2*tx + {0,1})
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    float bacc = 0.f;                                               // bvec[ti + threadIdx.x] on the tj == 0 column of blocks
-    for (int c0 = 0; c0 < C; c0 += 32) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < 32 * 32; e += 256) {
-            const int cc = e >> 5, kk = e & 31, c = c0 + cc;
-            const bool okc = c < C;
-            sa[cc][kk] = (okc && ti + kk < w) ? bf16_bits_to_f32(W[(size_t)c * w + ti + kk]) : 0.f;
-            sb[cc][kk] = (okc && tj + kk < w) ? bf16_bits_to_f32(W[(size_t)c * w + tj + kk]) : 0.f;
-        }
-        if (threadIdx.x < 32) { const int c = c0 + threadIdx.x; sq[threadIdx.x] = c < C ? qk[c] : 0.f; sk[threadIdx.x] = c < C ? qk[C + c] : 0.f; }
-        __syncthreads();
-#pragma unroll 8
-        for (int cc = 0; cc < 32; ++cc) {
-            const float q = sq[cc];
-            const float a0 = sa[cc][2 * ty] * q, a1 = sa[cc][2 * ty + 1] * q, b0 = sb[cc][2 * tx], b1 = sb[cc][2 * tx + 1];
-            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-        }
-        if (blockIdx.x == 0 && threadIdx.x < 32)
-#pragma unroll 8
-            for (int cc = 0; cc < 32; ++cc) bacc += sk[cc] * sa[cc][threadIdx.x];
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int k = ti + 2 * ty + r, kp = tj + 2 * tx;
-        if (k < w && kp + 1 < w) *reinterpret_cast<uint32_t*>(wd2 + (size_t)k * w + kp) = pack_bf16x2(-acc[r][0], -acc[r][1]);
-        else if (k < w && kp < w) wd2[(size_t)k * w + kp] = f32_to_bf16_bits(-acc[r][0]);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 32 && ti + threadIdx.x < w) bvec[ti + threadIdx.x] = bacc;
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
-int launch_bnlin_stats(hipStream_t st, const uint16_t* W, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
-                       const float* beta, float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
-    if (w % 4 != 0 || w > 2048) { set_error("bnlin: input width %d must be a multiple of 4 and <= 2048", w); return DALI_ERR_INVALID; }
-    hipLaunchKernelGGL(bnlin_stats_kernel, dim3((C + BL_CH - 1) / BL_CH), dim3(256), (size_t)BL_CH * w * sizeof(float), st, W, gram, m2, C, w, count, gamma, beta,
-                       rm, rv, momentum, eps, scale, shift, mean, invstd);
+// Wt = W^T [w][C] bf16 (the plain data-gradient image of the convolution); ut [w][C] fp32 and dot [w/32][C] fp32 are outputs the
+// backward / the finish kernel read
+int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
+                       const float* beta, float* rm, float* rv, float momentum, float eps, float* ut, float* dot, float* scale, float* shift,
+                       float* mean, float* invstd) {
+    if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
+    // Ut[k'][c] = sum_k G[k][k'] Wt[k][c]  (G symmetric: read as A[k][m = k']); dot[tile][c] = sum_{k' in tile} Ut[k'][c] Wt[k'][c]
+    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<float, false, false>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, Wt, C, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
+                       Wt, C, dot, C, (const float*)nullptr, (float*)nullptr);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnlin_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, st, dot, w / 32, Wt, m2, C, w, count, gamma, beta, rm, rv, momentum, eps,
+                       scale, shift, mean, invstd);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 
-int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* gram, const float* m2, const float* s_dz, int C,
+int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk) {
-    if (w % 4 != 0 || w > 2048 || (C & 7)) { set_error("bnlin: width %d must be a multiple of 4 and <= 2048, C %d a multiple of 8", w, C); return DALI_ERR_INVALID; }
-    hipLaunchKernelGGL(bnlin_row_kernel, dim3((C + BL_CH - 1) / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, slabs, splits, W, gram, m2, s_dz, C, w,
+    if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
+    hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, slabs, splits, W, ut, m2, s_dz, C, w,
                        count, scale, mean, invstd, dW, dgamma, dbeta, wd1, qk);
     DALI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnlin_m_kernel, dim3((w + 31) / 32, (w + 31) / 32), dim3(256), 0, st, W, qk, C, w, wd2, bvec);
+    // wd2 = -(W^T diag(Q) W) [w][w] (bf16), bvec = W^T Kc: A = B = W [K = C][w], scaled by Q along K; v = Kc
+    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<uint16_t, true, true>), dim3(w / 32, w / 32), dim3(256), 0, st, W, w, W, w, qk, C, (float*)nullptr, wd2, w,
+                       (const uint16_t*)nullptr, 0, (float*)nullptr, 0, qk + C, bvec);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -247,28 +276,35 @@ static GatherGeom bl_geom(int P, int Ck) {
 
 extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, const uint16_t* W, int P, int C, int w, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* gram, float* m2,
-                              float* scale, float* shift, float* mean, float* invstd) {
-    DALI_REQUIRE(ctx && a && W && gamma && beta && gram && m2 && scale && shift && mean && invstd, "dali_bnlin_fwd: null argument");
-    DALI_REQUIRE(P > 0 && C % 8 == 0 && w % 32 == 0, "dali_bnlin_fwd: C %% 8, w %% 32 (C=%d w=%d)", C, w);
+                              float* ut, float* scale, float* shift, float* mean, float* invstd) {
+    DALI_REQUIRE(ctx && a && W && gamma && beta && gram && m2 && ut && scale && shift && mean && invstd, "dali_bnlin_fwd: null argument");
+    DALI_REQUIRE(P > 0 && C % 32 == 0 && w % 32 == 0, "dali_bnlin_fwd: C %% 32, w %% 32 (C=%d w=%d)", C, w);
     hipStream_t st = (hipStream_t)stream;
     WGradArgs wa{};
     wa.dY = a; wa.X = a; wa.Cm = w; wa.P = P; wa.Ntot = w; wa.g = bl_geom(P, w);
     size_t wsb;
     wgrad_plan(w, w, P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
     const size_t b_cs = align_up(colsum_partial_floats(P, w) * 4, 256), b_sc = align_up(reduce_scratch_bytes(w, 1), 256);
-    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc));
+    const size_t b_wt = align_up((size_t)C * w * 2, 256), b_dot = align_up((size_t)(w / 32) * C * 4, 256);
+    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + b_wt + b_dot));
     if (!ws) return DALI_ERR_NOMEM;
     wa.partial = reinterpret_cast<float*>(ws);
+    char* p = ws + align_up(wsb, 256);
+    float* cs_partial = reinterpret_cast<float*>(p); p += b_cs;
+    double* scratch = reinterpret_cast<double*>(p); p += b_sc;
+    uint16_t* wt = reinterpret_cast<uint16_t*>(p); p += b_wt;
+    float* dot = reinterpret_cast<float*>(p);
     int rc;
     if ((rc = launch_igemm_wgrad(st, wa, gram, 0))) return rc;
-    if ((rc = launch_colsum(st, a, P, w, m2, reinterpret_cast<float*>(ws + align_up(wsb, 256)), reinterpret_cast<double*>(ws + align_up(wsb, 256) + b_cs)))) return rc;
-    return launch_bnlin_stats(st, W, gram, m2, C, w, (double)P, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    if ((rc = launch_colsum(st, a, P, w, m2, cs_partial, scratch))) return rc;
+    if ((rc = launch_weight_transpose(st, W, C, 1, w, wt))) return rc;
+    return launch_bnlin_stats(st, wt, gram, m2, C, w, (double)P, gamma, beta, running_mean, running_var, momentum, eps, ut, dot, scale, shift, mean, invstd);
 }
 
 extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, const uint16_t* a, const uint16_t* W, int P, int C, int w,
-                              const float* gram, const float* m2, const float* scale, const float* mean, const float* invstd, float* dW,
+                              const float* ut, const float* m2, const float* scale, const float* mean, const float* invstd, float* dW,
                               float* dgamma, float* dbeta, uint16_t* wd1, uint16_t* wd2, float* bvec) {
-    DALI_REQUIRE(ctx && dz && a && W && gram && m2 && scale && mean && invstd && dW && dgamma && dbeta && wd1 && wd2 && bvec, "dali_bnlin_bwd: null argument");
+    DALI_REQUIRE(ctx && dz && a && W && ut && m2 && scale && mean && invstd && dW && dgamma && dbeta && wd1 && wd2 && bvec, "dali_bnlin_bwd: null argument");
     DALI_REQUIRE(P > 0 && C % 32 == 0 && w % 32 == 0, "dali_bnlin_bwd: C %% 32, w %% 32 (C=%d w=%d)", C, w);
     hipStream_t st = (hipStream_t)stream;
     WGradArgs wa{};
@@ -287,5 +323,5 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     int rc;
     if ((rc = launch_colsum(st, dz, P, C, sdz, cs_partial, scratch))) return rc;
     if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;
-    return launch_bnlin_bwd(st, wa.partial, wa.splits, W, gram, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
+    return launch_bnlin_bwd(st, wa.partial, wa.splits, W, ut, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
 }

@@ -44,7 +44,8 @@ struct Block {
     // bn3 behind conv3 through the moments of a2 (bnlin.hip): blocks without a downsample branch never store raw3
     bool lin3 = false;
     float *gram = nullptr, *m2 = nullptr, *sdz = nullptr, *bvec = nullptr, *qk = nullptr;      // [w][w], [w], [cout], [w], [2][cout]
-    uint16_t* wd2 = nullptr;                                   // [w][w] second data-gradient image; the first one lives in c3.wt_bf16
+    float *ut = nullptr, *dot = nullptr;                       // (W3 gram)^T [w][cout] (forward -> backward), [w/32][cout] scratch
+    uint16_t *wd1 = nullptr, *wd2 = nullptr;                   // data-gradient images (A.W3)^T [w][cout] and -(W3^T diag(Q) W3) [w][w]
 };
 
 struct Arena {
@@ -207,7 +208,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
                 add_bn(net, b.bd, pre + ".downsample.1", planes * 4);
             }
             b.hout = b.c2.hout; b.wout = b.c2.wout;
-            b.lin3 = !b.has_ds && bnlin_on() && planes % 8 == 0;
+            b.lin3 = !b.has_ds && bnlin_on() && planes % 32 == 0;
             h = b.hout; w = b.wout; inpl = planes * 4;
             net->blocks.push_back(b);
         }
@@ -247,7 +248,8 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
         else {
             reserve(net, a, b.gram, (size_t)b.width * b.width * 4); reserve(net, a, b.m2, (size_t)b.width * 4);
             reserve(net, a, b.sdz, (size_t)b.cout * 4); reserve(net, a, b.bvec, (size_t)b.width * 4); reserve(net, a, b.qk, (size_t)b.cout * 8);
-            reserve(net, a, b.wd2, (size_t)b.width * b.width * 2);
+            reserve(net, a, b.wd2, (size_t)b.width * b.width * 2); reserve(net, a, b.wd1, (size_t)b.width * b.cout * 2);
+            reserve(net, a, b.ut, (size_t)b.width * b.cout * 4); reserve(net, a, b.dot, (size_t)(b.width / 32) * b.cout * 4);
             max_cs = std::max(max_cs, std::max(colsum_partial_floats((int)pout, b.cout), colsum_partial_floats((int)pout, b.width)) * 4);
             int sp, pps; size_t wsb;
             wgrad_plan(b.width, b.width, (int)pout, 512, &sp, &pps, &wsb, 1, 0);
@@ -352,7 +354,7 @@ extern "C" int dali_resnet_refresh_weights(dali_resnet* net, void* stream) {
     if (rc) return rc;
     std::vector<TransposeJob> jobs;                      // every conv's dgrad image [cin][r*s][cout], one launch
     for (auto& b : net->blocks) {
-        Conv* cs[4] = {&b.c1, &b.c2, b.lin3 ? nullptr : &b.c3, b.has_ds ? &b.cd : nullptr};      // lin3: c3's data-gradient image is built per step (A.W3)
+        Conv* cs[4] = {&b.c1, &b.c2, &b.c3, b.has_ds ? &b.cd : nullptr};
         for (Conv* c : cs)
             if (c) jobs.push_back(TransposeJob{c->w_bf16, c->wt_bf16, c->cout, c->r * c->s, c->cin, 0});
     }
@@ -465,8 +467,9 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                 wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
                 if ((rc = launch_igemm_wgrad(st, wa, b.gram, 0))) return rc;
                 if ((rc = launch_colsum(st, b.a2, Pout, b.width, b.m2, net->cs_partial, net->red_scratch))) return rc;
-                if ((rc = launch_bnlin_stats(st, b.c3.w_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
-                                             net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.b3.scale, b.b3.shift, b.b3.mean, b.b3.invstd))) return rc;
+                if ((rc = launch_bnlin_stats(st, b.c3.wt_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
+                                             net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.ut, b.dot, b.b3.scale, b.b3.shift, b.b3.mean,
+                                             b.b3.invstd))) return rc;
             } else if ((rc = bn_eval(net, st, b.b3))) return rc;
             IGemmArgs a{};
             a.W = b.c3.w_bf16; a.X = b.a2; a.O = b.y; a.Res = x; a.out_scale = b.b3.scale; a.out_shift = b.b3.shift; a.out_relu = 1;
@@ -509,11 +512,11 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         size_t wsb;
         wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
         if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;                       // slabs of G0 = dz^T a2
-        if ((rc = launch_bnlin_bwd(st, net->wgrad_slab, wa.splits, b.c3.w_bf16, b.gram, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
-                                   b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.c3.wt_bf16, b.wd2, b.bvec, b.qk))) return rc;
+        if ((rc = launch_bnlin_bwd(st, net->wgrad_slab, wa.splits, b.c3.w_bf16, b.ut, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
+                                   b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.wd1, b.wd2, b.bvec, b.qk))) return rc;
         d_a2 = next_gbuf(net, dz);
         scratch_a = next_gbuf(net, dz, d_a2);
-        if ((rc = conv_dgrad(net, st, b.c3, dz, nullptr, d_a2, nullptr, b.c3.wt_bf16, b.bvec))) return rc;      // dz (A.W3) + W3^T Kc
+        if ((rc = conv_dgrad(net, st, b.c3, dz, nullptr, d_a2, nullptr, b.wd1, b.bvec))) return rc;             // dz (A.W3) + W3^T Kc
         const Conv sq = square_conv(b.c3);
         if ((rc = conv_dgrad(net, st, sq, b.a2, d_a2, d_a2, nullptr, b.wd2, nullptr))) return rc;               // - a2 (W3^T diag(Q) W3), in place
     } else {

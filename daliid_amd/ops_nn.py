@@ -78,10 +78,11 @@ def bnlin_fwd(a, w, gamma, beta, running_mean=None, running_var=None, momentum=0
     P, wd = a.shape
     C = w.shape[0]
     dev = a.device
-    o = dict(gram=torch.empty(wd, wd, device=dev), m2=_f32(wd, dev), scale=_f32(C, dev), shift=_f32(C, dev), mean=_f32(C, dev), invstd=_f32(C, dev))
+    o = dict(gram=torch.empty(wd, wd, device=dev), m2=_f32(wd, dev), ut=torch.empty(wd, C, device=dev), scale=_f32(C, dev), shift=_f32(C, dev),
+             mean=_f32(C, dev), invstd=_f32(C, dev))
     _lib.check(_lib.lib().dali_bnlin_fwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(a, bf16, "a"), _lib.ptr(w, bf16, "w"), P, C, wd, _lib.ptr(gamma),
                                           _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var), momentum, eps, _lib.ptr(o["gram"]),
-                                          _lib.ptr(o["m2"]), _lib.ptr(o["scale"]), _lib.ptr(o["shift"]), _lib.ptr(o["mean"]), _lib.ptr(o["invstd"])),
+                                          _lib.ptr(o["m2"]), _lib.ptr(o["ut"]), _lib.ptr(o["scale"]), _lib.ptr(o["shift"]), _lib.ptr(o["mean"]), _lib.ptr(o["invstd"])),
                "dali_bnlin_fwd")
     return o
 
@@ -94,7 +95,7 @@ def bnlin_bwd(dz, a, w, fwd):
     o = dict(dW=torch.empty(C, wd, device=dev), dgamma=_f32(C, dev), dbeta=_f32(C, dev), wd1=torch.empty(wd, C, device=dev, dtype=bf16),
              wd2=torch.empty(wd, wd, device=dev, dtype=bf16), bvec=_f32(wd, dev))
     _lib.check(_lib.lib().dali_bnlin_bwd(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(dz, bf16, "dz"), _lib.ptr(a, bf16, "a"), _lib.ptr(w, bf16, "w"), P, C, wd,
-                                          _lib.ptr(fwd["gram"]), _lib.ptr(fwd["m2"]), _lib.ptr(fwd["scale"]), _lib.ptr(fwd["mean"]), _lib.ptr(fwd["invstd"]),
+                                          _lib.ptr(fwd["ut"]), _lib.ptr(fwd["m2"]), _lib.ptr(fwd["scale"]), _lib.ptr(fwd["mean"]), _lib.ptr(fwd["invstd"]),
                                           _lib.ptr(o["dW"]), _lib.ptr(o["dgamma"]), _lib.ptr(o["dbeta"]), _lib.ptr(o["wd1"]), _lib.ptr(o["wd2"]),
                                           _lib.ptr(o["bvec"])), "dali_bnlin_bwd")
     return o

@@ -131,17 +131,17 @@ int dali_conv1x1_fused(dali_ctx* ctx, void* stream, const uint16_t* x, const uin
                        const float* out_scale, const float* out_shift, const float* bias, const uint16_t* residual, int out_relu,
                        uint8_t* bits_out, const uint8_t* out_mask);
 /* Training-mode BatchNorm behind a 1x1 convolution WITHOUT the convolution's output (csrc/bnlin.hip): raw = a W^T is linear in
- * a [P][w] (bf16), so its batch statistics follow from gram = a^T a [w][w] and m2 = colsum(a) [w] (both returned, fp32; the backward
- * needs them again): mean = W m2 / P, E[raw^2] = diag(W gram W^T) / P.  Outputs scale = gamma*invstd, shift = beta - mean*scale,
+ * a [P][w] (bf16), so its batch statistics follow from gram = a^T a [w][w] and m2 = colsum(a) [w] (returned, fp32):
+ * mean = W m2 / P, E[raw^2] = diag(W gram W^T) / P; ut = (W gram)^T [w][C] (fp32) is returned for the backward, with m2.  Outputs scale = gamma*invstd, shift = beta - mean*scale,
  * mean, invstd [C]; running statistics updated like torch (nullable).  W bf16 [C][w]; C % 8 == 0, w % 32 == 0. */
 int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, const uint16_t* W, int P, int C, int w, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* gram, float* m2,
-                   float* scale, float* shift, float* mean, float* invstd);
+                   float* ut, float* scale, float* shift, float* mean, float* invstd);
 /* Its backward from the gradient dz [P][C] in front of the BatchNorm output: dW [C][w], dgamma, dbeta, and the two weight images of the
  * data gradient  d_a = dz wd1^T + a wd2^T + bvec  (wd1 = (scale.W)^T [w][C], wd2 = -(W^T diag(Q) W) [w][w], bvec = W^T Kc [w];
  * d_raw = scale dz + Kc - Q raw is nnops.hip's folded form of the BatchNorm backward). */
 int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, const uint16_t* a, const uint16_t* W, int P, int C, int w,
-                   const float* gram, const float* m2, const float* scale, const float* mean, const float* invstd, float* dW,
+                   const float* ut, const float* m2, const float* scale, const float* mean, const float* invstd, float* dW,
                    float* dgamma, float* dbeta, uint16_t* wd1, uint16_t* wd2, float* bvec);
 /* rows of the `stats` buffer for a given problem (depends on the tile configuration the launcher will pick). */
 int dali_conv2d_stat_tiles(int cout, int cin, int r, int s, int stride, int pad, int n, int ho, int wo, int fused_operand);
