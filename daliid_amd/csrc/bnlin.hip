@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bnlin_finish_kernel(const float* __restri
 // ---- backward, per group of BL_CH output channels: split-K slabs of G0 = dz^T a2 -> dgamma, dbeta, folded coefficients, dW, A.W ----
 // Ut = (W G)^T [w][C] was left by the forward's TN product.
 __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict__ slabs, int splits, const uint16_t* __restrict__ W,
-                                                         const float* __restrict__ Ut, const float* __restrict__ m2, const float* __restrict__ s_dz,
+                                                         const float* __restrict__ Ut, const float* __restrict__ m2, const float* __restrict__ s_partial, int s_rows,
                                                          int C, int w, double count, const float* __restrict__ scale, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float* __restrict__ dW, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, uint16_t* __restrict__ wd1, float* __restrict__ qk) {
@@ -188,17 +188,34 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict_
     __shared__ float coef[BL_CH][3];                        // A, Kc, Q
     const int c0 = blockIdx.x * BL_CH;                      // C % BL_CH == 0 (checked by the launcher)
     const size_t slab = (size_t)C * w;
-    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // fixed-order sum over the split-K slabs (deterministic), 4 loads in flight
-        const float* p = slabs + (size_t)c0 * w + e;
-        float acc = 0.f;
+    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // fixed-order sum over the split-K slabs (deterministic); 16 loads in flight:
+        const float* p = slabs + (size_t)c0 * w + e;        // with 4 the pass was latency-bound (30-46 us whatever the layer, up to 256 slabs)
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         int sidx = 0;
-        for (; sidx + 4 <= splits; sidx += 4) {
-            const float v0 = p[(size_t)sidx * slab], v1 = p[(size_t)(sidx + 1) * slab], v2 = p[(size_t)(sidx + 2) * slab], v3 = p[(size_t)(sidx + 3) * slab];
-            acc += v0; acc += v1; acc += v2; acc += v3;
+        for (; sidx + 16 <= splits; sidx += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(sidx + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
         }
-        for (; sidx < splits; ++sidx) acc += p[(size_t)sidx * slab];
-        g0[e] = acc;
+        for (; sidx < splits; ++sidx) acc[0] += p[(size_t)sidx * slab];
+        g0[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         wf[e] = bf16_bits_to_f32(W[(size_t)c0 * w + e]);
+    }
+    __shared__ double s_sum[BL_CH];
+    {   // s[c] = column sum of dz: finish the first-level partial rows (fp64, fixed order)
+        const int ch = threadIdx.x & (BL_CH - 1), sub = threadIdx.x / BL_CH;          // 8 channels x 32 row slices
+        double t = 0.0;
+        for (int r = sub; r < s_rows; r += 256 / BL_CH) t += (double)s_partial[(size_t)r * C + c0 + ch];
+        __shared__ double s_red[256 / BL_CH][BL_CH];
+        s_red[sub][ch] = t;
+        __syncthreads();
+        if (threadIdx.x < BL_CH) {
+            double a = 0.0;
+            for (int r = 0; r < 256 / BL_CH; ++r) a += s_red[r][threadIdx.x];
+            s_sum[threadIdx.x] = a;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict_
         t = block_sum_d(t, red);
         const int c = c0 + ch;
         if (threadIdx.x == 0) {
-            const double s = (double)s_dz[c], iv = (double)invstd[c], mn = (double)mean[c], a = (double)scale[c];
+            const double s = s_sum[ch], iv = (double)invstd[c], mn = (double)mean[c], a = (double)scale[c];
             const double dg = iv * (t - mn * s);                    // sum dz * xhat
             const double qq = a * iv * dg / count;
             dgamma[c] = (float)dg;
@@ -248,11 +265,11 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
     return DALI_OK;
 }
 
-int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
+int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const float* s_partial, int s_rows, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
-    hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, slabs, splits, W, ut, m2, s_dz, C, w,
+    hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, slabs, splits, W, ut, m2, s_partial, s_rows, C, w,
                        count, scale, mean, invstd, dW, dgamma, dbeta, wd1, qk);
     DALI_LAUNCH_CHECK();
     // wd2 = -(W^T diag(Q) W) [w][w] (bf16), bvec = W^T Kc: A = B = W [K = C][w], scaled by Q along K; v = Kc
@@ -311,17 +328,15 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     wa.dY = dz; wa.X = a; wa.Cm = C; wa.P = P; wa.Ntot = w; wa.g = bl_geom(P, w);
     size_t wsb;
     wgrad_plan(C, w, P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
-    const size_t b_cs = align_up(colsum_partial_floats(P, C) * 4, 256), b_sc = align_up(reduce_scratch_bytes(C, 1), 256), b_v = align_up((size_t)C * 4, 256);
-    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + 3 * b_v));
+    const size_t b_cs = align_up(colsum_partial_floats(P, C) * 4, 256), b_v = align_up((size_t)C * 4, 256);
+    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + 2 * b_v));
     if (!ws) return DALI_ERR_NOMEM;
     wa.partial = reinterpret_cast<float*>(ws);
     char* p = ws + align_up(wsb, 256);
     float* cs_partial = reinterpret_cast<float*>(p); p += b_cs;
-    double* scratch = reinterpret_cast<double*>(p); p += b_sc;
-    float* sdz = reinterpret_cast<float*>(p); p += b_v;
     float* qk = reinterpret_cast<float*>(p);
-    int rc;
-    if ((rc = launch_colsum(st, dz, P, C, sdz, cs_partial, scratch))) return rc;
+    int rc, s_rows = 0;
+    if ((rc = launch_colsum_partials(st, dz, P, C, cs_partial, &s_rows))) return rc;
     if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;
-    return launch_bnlin_bwd(st, wa.partial, wa.splits, W, ut, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
+    return launch_bnlin_bwd(st, wa.partial, wa.splits, W, ut, m2, cs_partial, s_rows, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
 }

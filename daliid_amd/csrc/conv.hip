@@ -395,6 +395,22 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
             sh4[i] = a.out_shift ? *reinterpret_cast<const float4*>(a.out_shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + c); sh4[i].x += b.x; sh4[i].y += b.y; sh4[i].z += b.z; sh4[i].w += b.w; }
         }
+        // the residual tile of BOTH halves is requested up front: the second half's loads fly while the first half is formed and stored
+        // (requested per half they exposed one HBM round trip per half: these kernels are short-K, their epilogue is most of their time)
+        constexpr bool PRE = NT == 256;          // (the 512-thread 128 x 256 kernel would leave its 128-register budget = two workgroups per CU)
+        uint4 rpre[2][ITERS];
+        if (PRE && a.Res) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lp = lp0 + it * (NT / CPR);
+                    const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
+                    rpre[h][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + gbase + (size_t)q * a.Cm * 2);
+                }
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
@@ -404,14 +420,17 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     const int lp = lp0 + it * (NT / CPR);
                     const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
                     const size_t rb = gbase + (size_t)q * a.Cm * 2;
-                    uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
+                    uint4 rv;
+                    if constexpr (PRE) rv = rpre[h][it];
+                    else rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
                     if (a.res_mask) {
                         const unsigned m = a.res_mask[rb >> 4];
                         rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
                     }
                     *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) = rv;
                 }
-                lds_barrier_vm();
+                if constexpr (PRE) lds_barrier();               // (the register dependence waits for the loads of this half only)
+                else lds_barrier_vm();
             }
 #pragma unroll
             for (int jj = 0; jj < HFN; ++jj) {
@@ -550,7 +569,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
 // (lds_void_ptr, DMA_OOB, dma_wait<N> live in gemm_tile.h: shared with eval.hip)
 
 template <int TM, int TN, int NSTAGE, int EPI = 0>        // EPI: 0 convolution, 1 linear-layer extras, 3 fused output stage (conv_epilogue_g)
-__global__ __launch_bounds__(256, (TM >= 128 ? 4 : 2)) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     // 128 x 128: <= 128 VGPRs (4 waves per SIMD); the 64 x 256 shape carries twice the per-lane gather state and would spill
     using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
     constexpr int FM = Cfg::FM, FN = Cfg::FN;

@@ -89,7 +89,8 @@ size_t linear_wgrad_slab_bytes(int rows, int K, int N);
 int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
                        const float* beta, float* rm, float* rv, float momentum, float eps, float* ut, float* dot, float* scale, float* shift,
                        float* mean, float* invstd);
-int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
+// s_partial [s_rows][C]: first-level column sums of dz (launch_colsum_partials); summed per channel in fp64 by the row kernel
+int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const float* s_partial, int s_rows, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk);
 
@@ -141,6 +142,7 @@ int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, c
                          const float* g32 = nullptr);
 size_t colsum_partial_floats(int rows, int C);
 int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out, float* partial, double* scratch);
+int launch_colsum_partials(hipStream_t st, const uint16_t* y, int rows, int C, float* partial, int* n_rows);
 // out = (res or 0) + scale[row / rows_per_sample] * branch   (DropPath per sample; C % 8 == 0)
 int launch_rowscale_add(hipStream_t st, const uint16_t* branch, const float* scale, int samples, int rows_per_sample, int C, const uint16_t* res,
                         uint16_t* out);

@@ -639,6 +639,16 @@ int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, c
     return DALI_OK;
 }
 size_t colsum_partial_floats(int rows, int C) { int rpb; const int rif = 256 / ((C / 8) < 256 ? (C / 8) : 256); return (size_t)rows_blocks(rows, rif, &rpb) * C; }
+// first level only: partial[*n_rows][C] per-block column sums; the caller finishes the sum (bnlin.hip's row kernel)
+int launch_colsum_partials(hipStream_t st, const uint16_t* y, int rows, int C, float* partial, int* n_rows) {
+    const int cpr = C / 8, rif = 256 / (cpr < 256 ? cpr : 256);
+    int rpb;
+    const int blocks = rows_blocks(rows, rif, &rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), (size_t)rif * C * sizeof(float), st, y, rows, C, rpb, partial);
+    DALI_LAUNCH_CHECK();
+    *n_rows = blocks;
+    return DALI_OK;
+}
 int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out, float* partial, double* scratch) {
     const int cpr = C / 8, rif = 256 / (cpr < 256 ? cpr : 256);
     int rpb;
