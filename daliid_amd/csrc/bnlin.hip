@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bnlin_finish_kernel(const float* __restri
 // ---- backward, per group of BL_CH output channels: split-K slabs of G0 = dz^T a2 -> dgamma, dbeta, folded coefficients, dW, A.W ----
 // Ut = (W G)^T [w][C] was left by the forward's TN product.
 __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict__ slabs, int splits, const uint16_t* __restrict__ W,
-                                                         const float* __restrict__ Ut, const float* __restrict__ m2, const float* __restrict__ s_partial, int s_rows,
+                                                         const float* __restrict__ Ut, const float* __restrict__ m2, const double* __restrict__ s_partial, int s_rows,
                                                          int C, int w, double count, const float* __restrict__ scale, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float* __restrict__ dW, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, uint16_t* __restrict__ wd1, float* __restrict__ qk) {
@@ -204,10 +204,10 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict_
         wf[e] = bf16_bits_to_f32(W[(size_t)c0 * w + e]);
     }
     __shared__ double s_sum[BL_CH];
-    {   // s[c] = column sum of dz: finish the first-level partial rows (fp64, fixed order)
+    {   // s[c] = column sum of dz: finish the second-level partial rows of reduce_partials (fp64, <= 64 rows, fixed order)
         const int ch = threadIdx.x & (BL_CH - 1), sub = threadIdx.x / BL_CH;          // 8 channels x 32 row slices
         double t = 0.0;
-        for (int r = sub; r < s_rows; r += 256 / BL_CH) t += (double)s_partial[(size_t)r * C + c0 + ch];
+        for (int r = sub; r < s_rows; r += 256 / BL_CH) t += s_partial[(size_t)r * C + c0 + ch];
         __shared__ double s_red[256 / BL_CH][BL_CH];
         s_red[sub][ch] = t;
         __syncthreads();
@@ -265,7 +265,7 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
     return DALI_OK;
 }
 
-int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const float* s_partial, int s_rows, int C,
+int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const double* s_partial, int s_rows, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
@@ -328,15 +328,17 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     wa.dY = dz; wa.X = a; wa.Cm = C; wa.P = P; wa.Ntot = w; wa.g = bl_geom(P, w);
     size_t wsb;
     wgrad_plan(C, w, P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
-    const size_t b_cs = align_up(colsum_partial_floats(P, C) * 4, 256), b_v = align_up((size_t)C * 4, 256);
-    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + 2 * b_v));
+    const size_t b_cs = align_up(colsum_partial_floats(P, C) * 4, 256), b_sc = align_up(reduce_scratch_bytes(C, 1), 256), b_v = align_up((size_t)C * 4, 256);
+    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + 2 * b_v));
     if (!ws) return DALI_ERR_NOMEM;
     wa.partial = reinterpret_cast<float*>(ws);
     char* p = ws + align_up(wsb, 256);
     float* cs_partial = reinterpret_cast<float*>(p); p += b_cs;
+    double* scratch = reinterpret_cast<double*>(p); p += b_sc;
     float* qk = reinterpret_cast<float*>(p);
-    int rc, s_rows = 0;
-    if ((rc = launch_colsum_partials(st, dz, P, C, cs_partial, &s_rows))) return rc;
+    int rc, n_rows = 0, s_rows = 0;
+    if ((rc = launch_colsum_partials(st, dz, P, C, cs_partial, &n_rows))) return rc;
+    if ((rc = reduce_partials(st, cs_partial, n_rows, C, scratch, &s_rows))) return rc;
     if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;
-    return launch_bnlin_bwd(st, wa.partial, wa.splits, W, ut, m2, cs_partial, s_rows, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
+    return launch_bnlin_bwd(st, wa.partial, wa.splits, W, ut, m2, scratch, s_rows, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
 }

@@ -89,8 +89,8 @@ size_t linear_wgrad_slab_bytes(int rows, int K, int N);
 int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
                        const float* beta, float* rm, float* rv, float momentum, float eps, float* ut, float* dot, float* scale, float* shift,
                        float* mean, float* invstd);
-// s_partial [s_rows][C]: first-level column sums of dz (launch_colsum_partials); summed per channel in fp64 by the row kernel
-int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const float* s_partial, int s_rows, int C,
+// s_partial [s_rows][C] (fp64): second-level column sums of dz (launch_colsum_partials + reduce_partials); the row kernel finishes them
+int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const double* s_partial, int s_rows, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk);
 

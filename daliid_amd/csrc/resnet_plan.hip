@@ -151,6 +151,13 @@ bool bnlin_on() {
     if (v == -1) { const char* e = getenv("DALI_BNLIN"); v = e ? atoi(e) : 1; }
     return v != 0;
 }
+// The scheme trades passes over [P][4w] tensors for products of size w^2: it pays where P is large against w (layer1 / layer2 at batch
+// 256: 0.5 / 0.13 M pixels against w = 64 / 128).  DALI_BNLIN_MAXW moves the limit (A/B aid; measured per limit in DESIGN.md).
+int bnlin_max_width() {
+    static int v = -1;
+    if (v == -1) { const char* e = getenv("DALI_BNLIN_MAXW"); v = e ? atoi(e) : 128; }
+    return v;
+}
 // a cin = cout = w 1x1 convolution on the grid of conv3: the shape of the Gram GEMM a2^T a2 and of the second data-gradient GEMM
 Conv square_conv(const Conv& c3) {
     Conv q = c3;
@@ -208,7 +215,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
                 add_bn(net, b.bd, pre + ".downsample.1", planes * 4);
             }
             b.hout = b.c2.hout; b.wout = b.c2.wout;
-            b.lin3 = !b.has_ds && bnlin_on() && planes % 32 == 0;
+            b.lin3 = !b.has_ds && bnlin_on() && planes % 32 == 0 && planes <= bnlin_max_width();
             h = b.hout; w = b.wout; inpl = planes * 4;
             net->blocks.push_back(b);
         }
@@ -505,15 +512,16 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
     uint16_t *d_a2, *d_rawd = nullptr, *scratch_a;
     if (b.lin3) {
         // bn3 + conv3 through the moments of a2 (bnlin.hip): no reduce / apply passes over [P][cout] tensors, raw3 does not exist
-        int s_rows = 0;
-        if ((rc = launch_colsum_partials(st, dz, Pout, b.cout, net->cs_partial, &s_rows))) return rc;       // the row kernel finishes the sum
+        int n_rows = 0, s_rows = 0;
+        if ((rc = launch_colsum_partials(st, dz, Pout, b.cout, net->cs_partial, &n_rows))) return rc;
+        if ((rc = reduce_partials(st, net->cs_partial, n_rows, b.cout, net->red_scratch, &s_rows))) return rc;   // the row kernel finishes the sum
         WGradArgs wa{};
         wa.dY = dz; wa.X = b.a2; wa.partial = net->wgrad_slab; wa.Cm = b.cout; wa.P = Pout; wa.Ntot = b.width;
         wa.g = conv_geom(b.c3, 0);
         size_t wsb;
         wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
         if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;                       // slabs of G0 = dz^T a2
-        if ((rc = launch_bnlin_bwd(st, net->wgrad_slab, wa.splits, b.c3.w_bf16, b.ut, b.m2, net->cs_partial, s_rows, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
+        if ((rc = launch_bnlin_bwd(st, net->wgrad_slab, wa.splits, b.c3.w_bf16, b.ut, b.m2, net->red_scratch, s_rows, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
                                    b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.wd1, b.wd2, b.bvec, b.qk))) return rc;
         d_a2 = next_gbuf(net, dz);
         scratch_a = next_gbuf(net, dz, d_a2);
