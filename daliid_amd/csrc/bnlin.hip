@@ -17,6 +17,7 @@
 // The sums are fp32 MFMA accumulations reduced in a fixed order and finished in fp64: deterministic, and closer to the fp32
 // reference than statistics of a bf16-rounded tensor.
 #include "kernels.h"
+#include <algorithm>
 
 namespace dali {
 
@@ -174,48 +175,22 @@ __global__ __launch_bounds__(256) void bnlin_finish_kernel(const float* __restri
     }
 }
 
-// ---- backward, per group of BL_CH output channels: split-K slabs of G0 = dz^T a2 -> dgamma, dbeta, folded coefficients, dW, A.W ----
-// Ut = (W G)^T [w][C] was left by the forward's TN product.
-__global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict__ slabs, int splits, const uint16_t* __restrict__ W,
-                                                         const float* __restrict__ Ut, const float* __restrict__ m2, const double* __restrict__ s_partial, int s_rows,
-                                                         int C, int w, double count, const float* __restrict__ scale, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ dW, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, uint16_t* __restrict__ wd1, float* __restrict__ qk) {
+// ---- backward, per group of BL_CH output channels: G0 = dz^T a2 (in dW, reduced) -> dgamma, dbeta, folded coefficients, dW in place, A.W ----
+// Ut = (W G)^T [w][C] was left by the forward's TN product; s_dz = colsum(dz).
+__global__ __launch_bounds__(256) void bnlin_row_kernel(const uint16_t* __restrict__ W, const float* __restrict__ Ut, const float* __restrict__ m2,
+                                                         const float* __restrict__ s_dz, int C, int w, double count, const float* __restrict__ scale,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dW,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, uint16_t* __restrict__ wd1,
+                                                         float* __restrict__ qk) {
     extern __shared__ __attribute__((aligned(16))) float bl_smem[];
     float* wf = bl_smem;                                    // [BL_CH][w]
     float* g0 = wf + BL_CH * w;                             // [BL_CH][w]
     __shared__ double red[4];
-    __shared__ float coef[BL_CH][3];                        // A, Kc, Q
+    __shared__ float coef[BL_CH][4];                        // A, Kc, Q, pad
     const int c0 = blockIdx.x * BL_CH;                      // C % BL_CH == 0 (checked by the launcher)
-    const size_t slab = (size_t)C * w;
-    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // fixed-order sum over the split-K slabs (deterministic); 16 loads in flight:
-        const float* p = slabs + (size_t)c0 * w + e;        // with 4 the pass was latency-bound (30-46 us whatever the layer, up to 256 slabs)
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int sidx = 0;
-        for (; sidx + 16 <= splits; sidx += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(sidx + u) * slab];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
-        }
-        for (; sidx < splits; ++sidx) acc[0] += p[(size_t)sidx * slab];
-        g0[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {
+        g0[e] = dW[(size_t)c0 * w + e];
         wf[e] = bf16_bits_to_f32(W[(size_t)c0 * w + e]);
-    }
-    __shared__ double s_sum[BL_CH];
-    {   // s[c] = column sum of dz: finish the second-level partial rows of reduce_partials (fp64, <= 64 rows, fixed order)
-        const int ch = threadIdx.x & (BL_CH - 1), sub = threadIdx.x / BL_CH;          // 8 channels x 32 row slices
-        double t = 0.0;
-        for (int r = sub; r < s_rows; r += 256 / BL_CH) t += s_partial[(size_t)r * C + c0 + ch];
-        __shared__ double s_red[256 / BL_CH][BL_CH];
-        s_red[sub][ch] = t;
-        __syncthreads();
-        if (threadIdx.x < BL_CH) {
-            double a = 0.0;
-            for (int r = 0; r < 256 / BL_CH; ++r) a += s_red[r][threadIdx.x];
-            s_sum[threadIdx.x] = a;
-        }
     }
     __syncthreads();
 #pragma unroll
@@ -225,7 +200,7 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const float* __restrict_
         t = block_sum_d(t, red);
         const int c = c0 + ch;
         if (threadIdx.x == 0) {
-            const double s = s_sum[ch], iv = (double)invstd[c], mn = (double)mean[c], a = (double)scale[c];
+            const double s = (double)s_dz[c], iv = (double)invstd[c], mn = (double)mean[c], a = (double)scale[c];
             const double dg = iv * (t - mn * s);                    // sum dz * xhat
             const double qq = a * iv * dg / count;
             dgamma[c] = (float)dg;
@@ -265,11 +240,11 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
     return DALI_OK;
 }
 
-int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const double* s_partial, int s_rows, int C,
+int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
-    hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, slabs, splits, W, ut, m2, s_partial, s_rows, C, w,
+    hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, W, ut, m2, s_dz, C, w,
                        count, scale, mean, invstd, dW, dgamma, dbeta, wd1, qk);
     DALI_LAUNCH_CHECK();
     // wd2 = -(W^T diag(Q) W) [w][w] (bf16), bvec = W^T Kc: A = B = W [K = C][w], scaled by Q along K; v = Kc
@@ -301,7 +276,8 @@ extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, co
     wa.dY = a; wa.X = a; wa.Cm = w; wa.P = P; wa.Ntot = w; wa.g = bl_geom(P, w);
     size_t wsb;
     wgrad_plan(w, w, P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
-    const size_t b_cs = align_up(colsum_partial_floats(P, w) * 4, 256), b_sc = align_up(reduce_scratch_bytes(w, 1), 256);
+    const bool fused_cs = wgrad_colsum_supported(w, w, 1, P);
+    const size_t b_cs = align_up(std::max(colsum_partial_floats(P, w), (size_t)wa.splits * w) * 4, 256), b_sc = align_up(reduce_scratch_bytes(w, 1), 256);
     const size_t b_wt = align_up((size_t)C * w * 2, 256), b_dot = align_up((size_t)(w / 32) * C * 4, 256);
     char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + b_wt + b_dot));
     if (!ws) return DALI_ERR_NOMEM;
@@ -312,8 +288,10 @@ extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, co
     uint16_t* wt = reinterpret_cast<uint16_t*>(p); p += b_wt;
     float* dot = reinterpret_cast<float*>(p);
     int rc;
+    if (fused_cs) wa.colsum = cs_partial;
     if ((rc = launch_igemm_wgrad(st, wa, gram, 0))) return rc;
-    if ((rc = launch_colsum(st, a, P, w, m2, cs_partial, scratch))) return rc;
+    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, m2, (size_t)w, wa.splits, 0))) return rc; }
+    else if ((rc = launch_colsum(st, a, P, w, m2, cs_partial, scratch))) return rc;
     if ((rc = launch_weight_transpose(st, W, C, 1, w, wt))) return rc;
     return launch_bnlin_stats(st, wt, gram, m2, C, w, (double)P, gamma, beta, running_mean, running_var, momentum, eps, ut, dot, scale, shift, mean, invstd);
 }
@@ -328,17 +306,21 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     wa.dY = dz; wa.X = a; wa.Cm = C; wa.P = P; wa.Ntot = w; wa.g = bl_geom(P, w);
     size_t wsb;
     wgrad_plan(C, w, P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
-    const size_t b_cs = align_up(colsum_partial_floats(P, C) * 4, 256), b_sc = align_up(reduce_scratch_bytes(C, 1), 256), b_v = align_up((size_t)C * 4, 256);
-    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + 2 * b_v));
+    const bool fused_cs = wgrad_colsum_supported(C, w, 1, P);
+    const size_t b_cs = align_up(std::max(colsum_partial_floats(P, C), (size_t)wa.splits * C) * 4, 256), b_sc = align_up(reduce_scratch_bytes(C, 1), 256);
+    const size_t b_v = align_up((size_t)C * 4, 256);
+    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + 3 * b_v));
     if (!ws) return DALI_ERR_NOMEM;
     wa.partial = reinterpret_cast<float*>(ws);
     char* p = ws + align_up(wsb, 256);
     float* cs_partial = reinterpret_cast<float*>(p); p += b_cs;
     double* scratch = reinterpret_cast<double*>(p); p += b_sc;
+    float* sdz = reinterpret_cast<float*>(p); p += b_v;
     float* qk = reinterpret_cast<float*>(p);
-    int rc, n_rows = 0, s_rows = 0;
-    if ((rc = launch_colsum_partials(st, dz, P, C, cs_partial, &n_rows))) return rc;
-    if ((rc = reduce_partials(st, cs_partial, n_rows, C, scratch, &s_rows))) return rc;
-    if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;
-    return launch_bnlin_bwd(st, wa.partial, wa.splits, W, ut, m2, scratch, s_rows, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
+    int rc;
+    if (fused_cs) wa.colsum = cs_partial;
+    if ((rc = launch_igemm_wgrad(st, wa, dW, 0))) return rc;                       // G0 -> dW
+    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, sdz, (size_t)C, wa.splits, 0))) return rc; }
+    else if ((rc = launch_colsum(st, dz, P, C, sdz, cs_partial, scratch))) return rc;
+    return launch_bnlin_bwd(st, W, ut, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
 }

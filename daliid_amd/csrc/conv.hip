@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WGradArgs a, int tiles
 
 // wgrad, LDS-DMA version (the one the net plan uses): same tile / fragment scheme as igemm_wgrad_kernel, operands
 // streamed by `buffer_load_dwordx4 ... lds` (1 KiB block = 4 pixel rows x 256 B), swizzle applied on the source chunk.
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int tiles_m, int tiles_n) {
     constexpr int TILE = 32 * 128;
     __shared__ __attribute__((aligned(16))) uint16_t smem[3 * 2 * TILE];          // 3-stage ring, 48 KiB
@@ -1308,6 +1309,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // COLSUM: column sums of dY over this split's pixels = one more MFMA per A fragment against an all-ones B operand (every column of
+    // the 16 x 16 result is the sum); only the n-tile-0 / wn-0 waves, whose A fragments cover each channel of the m tile exactly once
+    const bool do_cs = COLSUM && tn == 0 && wn == 0;
+    f32x4_t cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    typedef short ones_vec_t __attribute__((ext_vector_type(8)));
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_vec_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
     if (ksteps > 0) {                                   // same 3-stage ring / counted-vmcnt schedule as igemm_conv_dma_kernel
         issue(0, 0);
@@ -1337,6 +1346,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
             }
+            if constexpr (COLSUM) if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, cs[i], 0, 0, 0);
+            }
             if (kt + 2 < ksteps) dma_wait<4>(); else dma_wait<0>();
             __builtin_amdgcn_s_barrier();
             st_cur = (st_cur == 2) ? 0 : st_cur + 1;
@@ -1356,6 +1369,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_dma_kernel(WGradArgs a, int t
                 if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
             }
         }
+    if constexpr (COLSUM) if (do_cs && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
+                if (m < a.Cm) a.colsum[(size_t)ks * a.Cm + m] = cs[i][rr];
+            }
+    }
     if (a.stamps) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2179,6 +2201,10 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const bool halo_ok = a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && a.g.mode == 0 && args.g.lw >= 0 && args.g.lhw >= 7 &&
                          a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck;
     const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P, halo_ok ? a.g.Wout : 0);
+    if (a.colsum && !(wcfg == 0 && dma_ok && !a.in_scale)) {
+        set_error("wgrad: column sums ride on the 128 x 128 LDS-DMA kernel only (wgrad_colsum_supported)");
+        return DALI_ERR_INVALID;
+    }
     if (!a.in_scale && dma_ok && wcfg == 3) {
         const int tm3 = (a.Cm + 127) / 128, tn3 = a.g.Ck / 64;
         const int lds = 3 * W3_STAGE * 2;            // 3 stages x 24 KiB (4 and 5 measured the same, before and after the inline-asm reads: the
@@ -2200,16 +2226,25 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
         if (wgrad_spec(a.Cm, a.Ntot)) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
         else hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm2, tn2);
     } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
-    else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
+    else if (dma_ok && a.colsum) hipLaunchKernelGGL(igemm_wgrad_dma_kernel<true>, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
+    else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel<false>, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     }
     DALI_LAUNCH_CHECK();
     if (!out) return DALI_OK;                       // the caller reduces the slabs itself
-    const size_t elems = (size_t)a.Cm * a.Ntot, chunks = (elems + 3) / 4;
+    return launch_splitk_reduce(st, a.partial, out, (size_t)a.Cm * a.Ntot, a.splits, accumulate);
+}
+
+bool wgrad_colsum_supported(int Cm, int Ntot, int taps, int P) {
+    return wgrad_pick_cfg(Cm, Ntot, taps, P, 0) == 0 && (long long)P * Cm * 2 < 0x7ff00000ll && (long long)P * Ntot * 2 < 0x7ff00000ll;
+}
+
+int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate) {
+    const size_t chunks = (elems + 3) / 4;
     const unsigned rblocks = (unsigned)((chunks + 63) / 64);
-    if (a.splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(rblocks), dim3(1024), 0, st, a.partial, out, elems, a.splits, accumulate);
-    else if (a.splits >= 2) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, st, a.partial, out, elems, a.splits, accumulate);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, a.partial, out, elems, a.splits, accumulate);
+    if (splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(rblocks), dim3(1024), 0, st, partial, out, elems, splits, accumulate);
+    else if (splits >= 2) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, st, partial, out, elems, splits, accumulate);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, partial, out, elems, splits, accumulate);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }

@@ -58,6 +58,8 @@ struct WGradArgs {
     int splits, pix_per_split;    // pix_per_split multiple of 32
     GatherGeom g;
     unsigned long long* stamps;   // diagnostic, as in IGemmArgs
+    float* colsum;                // optional [splits][Cm]: per-split column sums over the pixels of dY, by one extra MFMA per fragment against a
+                                  // ones operand in the n-tile-0 workgroups (128 x 128 kernel only: wgrad_colsum_supported); bnlin.hip's s / m2
 };
 
 
@@ -73,8 +75,11 @@ int igemm_conv_stat_tiles(int Cm, int P, int K);
 // taps = R*S of the convolution (1 for 1x1 convolutions and linear layers): selects the tile shape
 // halo_w = output width of a 3x3 / stride 1 / pad 1 convolution whose H*W is a power of two (0 otherwise): enables the halo kernel
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps = 1, int halo_w = 0);
-// out == nullptr: leave the split-K slabs in a.partial ([splits][Cm][Ntot]) for the caller to reduce (bnlin.hip)
+// out == nullptr: leave the split-K slabs in a.partial ([splits][Cm][Ntot]) for the caller to reduce
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
+bool wgrad_colsum_supported(int Cm, int Ntot, int taps, int P);
+// out[e] (+)= sum_k partial[k][e], fixed order
+int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate);
 
 int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,
                       uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N);
@@ -89,8 +94,8 @@ size_t linear_wgrad_slab_bytes(int rows, int K, int N);
 int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
                        const float* beta, float* rm, float* rv, float momentum, float eps, float* ut, float* dot, float* scale, float* shift,
                        float* mean, float* invstd);
-// s_partial [s_rows][C] (fp64): second-level column sums of dz (launch_colsum_partials + reduce_partials); the row kernel finishes them
-int launch_bnlin_bwd(hipStream_t st, const float* slabs, int splits, const uint16_t* W, const float* ut, const float* m2, const double* s_partial, int s_rows, int C,
+// dW holds G0 = dz^T a (the reduced weight-gradient GEMM) on entry and the weight gradient on return; s_dz = colsum(dz) [C]
+int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk);
 

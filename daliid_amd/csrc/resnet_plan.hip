@@ -43,7 +43,7 @@ struct Block {
                                                                 // apply-on-load repeats the VALU work per tap and per M-tile)
     // bn3 behind conv3 through the moments of a2 (bnlin.hip): blocks without a downsample branch never store raw3
     bool lin3 = false;
-    float *gram = nullptr, *m2 = nullptr, *bvec = nullptr, *qk = nullptr;                      // [w][w], [w], [w], [2][cout]
+    float *gram = nullptr, *m2 = nullptr, *sdz = nullptr, *bvec = nullptr, *qk = nullptr;      // [w][w], [w], [cout], [w], [2][cout]
     float *ut = nullptr, *dot = nullptr;                       // (W3 gram)^T [w][cout] (forward -> backward), [w/32][cout] scratch
     uint16_t *wd1 = nullptr, *wd2 = nullptr;                   // data-gradient images (A.W3)^T [w][cout] and -(W3^T diag(Q) W3) [w][w]
 };
@@ -254,13 +254,16 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
         if (!b.lin3) reserve(net, a, b.raw3, pout * b.cout * 2);
         else {
             reserve(net, a, b.gram, (size_t)b.width * b.width * 4); reserve(net, a, b.m2, (size_t)b.width * 4);
-            reserve(net, a, b.bvec, (size_t)b.width * 4); reserve(net, a, b.qk, (size_t)b.cout * 8);
+            reserve(net, a, b.sdz, (size_t)b.cout * 4); reserve(net, a, b.bvec, (size_t)b.width * 4); reserve(net, a, b.qk, (size_t)b.cout * 8);
             reserve(net, a, b.wd2, (size_t)b.width * b.width * 2); reserve(net, a, b.wd1, (size_t)b.width * b.cout * 2);
             reserve(net, a, b.ut, (size_t)b.width * b.cout * 4); reserve(net, a, b.dot, (size_t)(b.width / 32) * b.cout * 4);
             max_cs = std::max(max_cs, std::max(colsum_partial_floats((int)pout, b.cout), colsum_partial_floats((int)pout, b.width)) * 4);
             int sp, pps; size_t wsb;
             wgrad_plan(b.width, b.width, (int)pout, 512, &sp, &pps, &wsb, 1, 0);
             max_slab = std::max(max_slab, wsb);
+            max_cs = std::max(max_cs, (size_t)sp * b.width * 4);                    // per-split column sums riding on the GEMMs
+            wgrad_plan(b.cout, b.width, (int)pout, 512, &sp, &pps, &wsb, 1, 0);
+            max_cs = std::max(max_cs, (size_t)sp * b.cout * 4);
         }
         reserve(net, a, b.y, pout * b.cout * 2);
         reserve(net, a, b.ybits, pout * b.cout / 8);
@@ -472,8 +475,11 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                 wa.g = conv_geom(sq, 0);
                 size_t wsb;
                 wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
+                const bool fused_cs = wgrad_colsum_supported(wa.Cm, wa.Ntot, 1, wa.P);      // m2 = colsum(a2) rides on the Gram GEMM
+                if (fused_cs) wa.colsum = net->cs_partial;
                 if ((rc = launch_igemm_wgrad(st, wa, b.gram, 0))) return rc;
-                if ((rc = launch_colsum(st, b.a2, Pout, b.width, b.m2, net->cs_partial, net->red_scratch))) return rc;
+                if (fused_cs) { if ((rc = launch_splitk_reduce(st, net->cs_partial, b.m2, (size_t)b.width, wa.splits, 0))) return rc; }
+                else if ((rc = launch_colsum(st, b.a2, Pout, b.width, b.m2, net->cs_partial, net->red_scratch))) return rc;
                 if ((rc = launch_bnlin_stats(st, b.c3.wt_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
                                              net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.ut, b.dot, b.b3.scale, b.b3.shift, b.b3.mean,
                                              b.b3.invstd))) return rc;
@@ -512,16 +518,17 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
     uint16_t *d_a2, *d_rawd = nullptr, *scratch_a;
     if (b.lin3) {
         // bn3 + conv3 through the moments of a2 (bnlin.hip): no reduce / apply passes over [P][cout] tensors, raw3 does not exist
-        int n_rows = 0, s_rows = 0;
-        if ((rc = launch_colsum_partials(st, dz, Pout, b.cout, net->cs_partial, &n_rows))) return rc;
-        if ((rc = reduce_partials(st, net->cs_partial, n_rows, b.cout, net->red_scratch, &s_rows))) return rc;   // the row kernel finishes the sum
         WGradArgs wa{};
         wa.dY = dz; wa.X = b.a2; wa.partial = net->wgrad_slab; wa.Cm = b.cout; wa.P = Pout; wa.Ntot = b.width;
         wa.g = conv_geom(b.c3, 0);
         size_t wsb;
         wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
-        if ((rc = launch_igemm_wgrad(st, wa, nullptr, 0))) return rc;                       // slabs of G0 = dz^T a2
-        if ((rc = launch_bnlin_bwd(st, net->wgrad_slab, wa.splits, b.c3.w_bf16, b.ut, b.m2, net->red_scratch, s_rows, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
+        const bool fused_cs = wgrad_colsum_supported(wa.Cm, wa.Ntot, 1, wa.P);              // s = colsum(dz) rides on the weight-gradient GEMM
+        if (fused_cs) wa.colsum = net->cs_partial;
+        if ((rc = launch_igemm_wgrad(st, wa, net->G + b.c3.w_off, 0))) return rc;           // G0 = dz^T a2 into the gradient slot; finished in place below
+        if (fused_cs) { if ((rc = launch_splitk_reduce(st, net->cs_partial, b.sdz, (size_t)b.cout, wa.splits, 0))) return rc; }
+        else if ((rc = launch_colsum(st, dz, Pout, b.cout, b.sdz, net->cs_partial, net->red_scratch))) return rc;
+        if ((rc = launch_bnlin_bwd(st, b.c3.w_bf16, b.ut, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
                                    b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.wd1, b.wd2, b.bvec, b.qk))) return rc;
         d_a2 = next_gbuf(net, dz);
         scratch_a = next_gbuf(net, dz, d_a2);

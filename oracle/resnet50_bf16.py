@@ -58,6 +58,16 @@ def _bn_train(u, uq, bn, eps=1e-5):
     return uq * scale.view(shp) + shift.view(shp)
 
 
+def stores_raw3(blk):
+    """Does the HIP plan store conv3's output of this bottleneck in bf16?  Not where bn3 runs through the moments of a2 (csrc/bnlin.hip):
+    blocks without a downsample branch whose width is a multiple of 32 and at most DALI_BNLIN_MAXW (default 128; resnet_plan.hip)."""
+    import os
+    if blk.downsample is not None or os.environ.get("DALI_BNLIN", "1") == "0":
+        return True
+    w = blk.conv3.in_channels
+    return not (w % 32 == 0 and w <= int(os.environ.get("DALI_BNLIN_MAXW", "128")))
+
+
 def _conv(x, conv):
     return F.conv2d(x, QW(conv.weight), stride=conv.stride, padding=conv.padding)
 
@@ -75,8 +85,8 @@ def forward_matched(model, x):
             u2 = _conv(a1, blk.conv2)
             a2 = Q(F.relu(_bn_train(u2, Q(u2), blk.bn2)))
             u3 = _conv(a2, blk.conv3)
-            # blocks without a downsample branch: conv3's output is never stored (csrc/bnlin.hip), bn3 acts on the fp32 accumulators
-            out = _bn_train(u3, Q(u3) if blk.downsample is not None else u3, blk.bn3)
+            # where conv3's output is never stored (csrc/bnlin.hip) bn3 acts on the fp32 accumulators
+            out = _bn_train(u3, Q(u3) if stores_raw3(blk) else u3, blk.bn3)
             if blk.downsample is not None:
                 ud = _conv(x, blk.downsample[0])
                 idn = _bn_train(ud, Q(ud), blk.downsample[1])

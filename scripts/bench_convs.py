@@ -22,6 +22,11 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3   # us
 tot = {"fwd": 0, "dgrad": 0, "wgrad": 0, "roof": 0}
+MD = os.environ.get("MD")          # MD=<path>: also write the per-layer roofline table (profiles/rNN_conv_layers.md)
+md = ["# Per-layer implicit-GEMM kernels at the ResNet-50-ReID shapes (batch %d, 256x128), standalone launches\n" % B,
+      "`python scripts/bench_convs.py` on MI355X: every conv of the net as forward / data-gradient / weight-gradient (incl. its split-K reduce), HIP-event "
+      "time per launch, against `max(FLOP / 2.5 PFLOP/s, (input + output bytes) / 6 TB/s)`; GB/s = those algorithmic bytes / time.\n",
+      "| layer | x | M=pixels | N=Cout | K | GFLOP | pass | us | TFLOP/s | GB/s | binding roof | frac of roof |", "|---|---:|---:|---:|---:|---:|---|---:|---:|---:|---|---:|"]
 print("%-14s %8s | %9s %9s %9s | %8s %8s  (us; roof = max(flops/2.5PF, bytes/6TB/s) per pass)" % ("layer", "GFLOP", "fwd", "dgrad", "wgrad", "roof", "x cnt"))
 for name, H, W, cin, cout, k, st, cnt in L:
     pad = k // 2
@@ -39,4 +44,12 @@ for name, H, W, cin, cout, k, st, cnt in L:
     tw = timeit(lambda: nn.conv2d_wgrad(x, dy, (k, k), st, pad))
     print("%-14s %8.1f | %9.1f %9.1f %9.1f | %8.1f x%d   eff fwd %.0f%% dg %.0f%% wg %.0f%%" % (name, fl / 1e9, tf, td, tw, roof, cnt, 100 * roof / tf, 100 * roof / td, 100 * roof / tw))
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt; tot["roof"] += roof * cnt
+    bound = "MFMA" if fl / 2.5e15 >= byt / 6e12 else "HBM"
+    for pname, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw)):
+        md.append("| %s | %d | %d | %d | %d | %.1f | %s | %.1f | %.0f | %.0f | %s | %.2f |" % (name, cnt, B * ho * wo, cout, cin * k * k, fl / 1e9, pname, t, fl / t / 1e6,
+                                                                                          byt / t / 1e3, bound, roof / t))
 print("totals (ms): fwd %.2f dgrad %.2f wgrad %.2f ; roof per pass %.2f" % (tot["fwd"] / 1e3, tot["dgrad"] / 1e3, tot["wgrad"] / 1e3, tot["roof"] / 1e3))
+if MD:
+    md.append("\nTotals over the net (x count): forward %.2f ms, data gradient %.2f ms, weight gradient %.2f ms; sum of the per-layer roofs %.2f ms per pass."
+              % (tot["fwd"] / 1e3, tot["dgrad"] / 1e3, tot["wgrad"] / 1e3, tot["roof"] / 1e3))
+    open(MD, "w").write("\n".join(md) + "\n")

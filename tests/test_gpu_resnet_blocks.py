@@ -28,9 +28,9 @@ def block_forward_matched(blk, x):
     u1 = M._conv(x, blk.conv1); a1 = M.Q(F.relu(M._bn_train(u1, M.Q(u1), blk.bn1)))
     u2 = M._conv(a1, blk.conv2); a2 = M.Q(F.relu(M._bn_train(u2, M.Q(u2), blk.bn2)))
     u3 = M._conv(a2, blk.conv3)
-    # blocks without a downsample branch never store conv3's output (bn3 through the moments of a2, csrc/bnlin.hip): bn3 acts on the fp32
-    # accumulators there; with a downsample branch raw3 is stored in bf16 as before
-    out = M._bn_train(u3, M.Q(u3) if blk.downsample is not None else u3, blk.bn3)
+    # narrow blocks without a downsample branch never store conv3's output (bn3 through the moments of a2, csrc/bnlin.hip): bn3 acts on the
+    # fp32 accumulators there; elsewhere raw3 is stored in bf16 as before
+    out = M._bn_train(u3, M.Q(u3) if M.stores_raw3(blk) else u3, blk.bn3)
     if blk.downsample is not None:
         ud = M._conv(x, blk.downsample[0]); idn = M._bn_train(ud, M.Q(ud), blk.downsample[1])
     else:
