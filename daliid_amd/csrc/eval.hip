@@ -335,7 +335,7 @@ __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __re
 // entries per query in the first launch (16 KiB of LDS: 8+ workgroups per CU); queries with more are flagged and redone by a
 // second launch with room for RANK_PMAX; beyond that DALI_ERR_LIMIT through status[0].
 // ------------------------------------------------------------------------------------------------
-constexpr int RANK_PSMALL = 512, RANK_PMAX = 4096;
+constexpr int RANK_PSMALL = 512, RANK_PMAX = 4096, RANK_BINS = 1024;
 constexpr int RANK_MAX_PID_RANGE = 1 << 20;      // identity codes must span at most this range (the mirrors pass dense codes): status 2 otherwise
 
 __device__ __forceinline__ bool key_less(float da, int ia, float db, int ib) {
@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* __restrict
                                                           float* __restrict__ ap_out, int32_t* __restrict__ first_rank,
                                                           int32_t* __restrict__ pending, int32_t* __restrict__ status) {
     __shared__ unsigned long long s_key[PCAP];    // (orderable distance bits << 32) | gallery index: one 8-byte LDS read per compare
+    __shared__ unsigned s_cell[RANK_BINS];
     __shared__ int s_cnt[PCAP + 1];
     __shared__ int s_junk[PCAP];
     __shared__ int s_n, s_nj;
@@ -464,33 +465,55 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* __restrict
             __syncthreads();
         }
     }
-    // 3. bin EVERY gallery entry by the number of matches with a smaller key (only the distance row is read:
-    //    4 bytes per pair, coalesced 16 B per lane), then take the junk entries back out of their bins.
-    //    The searches are branch-free lower bounds over the power-of-two padded key array (log2(npad) steps, the same for
-    //    every lane) and run four at a time in lockstep, so four independent LDS reads are in flight per step: a
-    //    data-dependent binary search per entry left the pass bound by LDS latency (8.3 ms for 10k x 100k random distances).
+    // 3. bin EVERY gallery entry by the number of matches with a smaller key (only the distance row is read: 4 bytes per pair, coalesced
+    //    16 B per lane), then take the junk entries back out of their bins.
+    //    The lower bound over the sorted matches is NOT searched per entry (7 dependent LDS reads per entry at ~100 matches left the pass
+    //    LDS-bound on random distances: 1.7 ms for 10k x 100k against 0.8 ms of HBM time).  The distance axis between the first and the
+    //    last match is cut into RANK_BINS uniform cells; s_cell[c] = (matches in lower cells) | (matches in cell c) << 16.  An entry reads
+    //    its cell's word: that IS its lower bound unless the cell holds matches itself (about one cell in ten), where a short search
+    //    inside the cell's matches finishes it.  floor((d - lo) * scale) is monotone in d, so cells never reorder keys.
     const unsigned long long last_key = s_key[np - 1];
-    auto bin4 = [&](const float4 v, int g, int delta) {
-        const unsigned long long k0 = rank_key(v.x, g), k1 = rank_key(v.y, g + 1), k2 = rank_key(v.z, g + 2), k3 = rank_key(v.w, g + 3);
-        const bool a0 = k0 <= last_key, a1 = k1 <= last_key, a2 = k2 <= last_key, a3 = k3 <= last_key;   // beyond the last match: affects no position
-        if (!(a0 | a1 | a2 | a3)) return;
-        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        for (int step = npad >> 1; step >= 1; step >>= 1) {
-            const unsigned long long m0 = s_key[p0 + step - 1], m1 = s_key[p1 + step - 1], m2 = s_key[p2 + step - 1], m3 = s_key[p3 + step - 1];
-            p0 += (m0 < k0) ? step : 0; p1 += (m1 < k1) ? step : 0; p2 += (m2 < k2) ? step : 0; p3 += (m3 < k3) ? step : 0;
+    auto key_dist = [](unsigned long long k) { unsigned b = (unsigned)(k >> 32); b = (b & 0x80000000u) ? (b ^ 0x80000000u) : ~b; return __uint_as_float(b); };
+    const float dlo = key_dist(s_key[0]), dhi = key_dist(last_key);
+    const float cscale = dhi > dlo ? (float)RANK_BINS / (dhi - dlo) : 0.f;
+    auto cell_of = [&](float dn) { const unsigned c = (unsigned)(int)((dn - dlo) * cscale); return (int)(c < (unsigned)RANK_BINS ? c : RANK_BINS - 1); };   // (always in bounds)
+    for (int t = tid; t < RANK_BINS; t += 256) s_cell[t] = 0;
+    __syncthreads();
+    for (int t = tid; t < np; t += 256) atomicAdd(&s_cell[cell_of(key_dist(s_key[t]))], 1u << 16);
+    __syncthreads();
+    {   // exclusive scan of the per-cell match counts into the low halves (RANK_BINS = 4 * 256: four cells per thread)
+        unsigned c4[4], run = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c4[u] = s_cell[tid * 4 + u] >> 16; run += c4[u]; }
+        s_scan[tid] = (int)run;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int add = (tid >= o) ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
         }
-        if (a0) atomicAdd(&s_cnt[p0], delta);
-        if (a1) atomicAdd(&s_cnt[p1], delta);
-        if (a2) atomicAdd(&s_cnt[p2], delta);
-        if (a3) atomicAdd(&s_cnt[p3], delta);
+        unsigned base = (unsigned)s_scan[tid] - run;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s_cell[tid * 4 + u] = base | (c4[u] << 16); base += c4[u]; }
+        __syncthreads();
+    }
+    auto lower_bound_in = [&](unsigned long long k, float dn) {          // number of matches with a key below k, for dlo <= dn and k <= last_key
+        const unsigned cw = s_cell[cell_of(dn)];
+        int p = (int)(cw & 0xffffu), len = (int)(cw >> 16);
+        while (len > 0) {                                               // only cells that hold matches: a search among THEIR keys
+            const int half = len >> 1;
+            if (s_key[p + half] < k) { p += half + 1; len -= half + 1; } else len = half;
+        }
+        return p;
     };
     auto bin = [&](float d, int g, int delta) {
+        const float dn = d + 0.0f;
         const unsigned long long k = rank_key(d, g);
-        if (k > last_key) return;
-        int pos = 0;
-        for (int step = npad >> 1; step >= 1; step >>= 1) pos += (s_key[pos + step - 1] < k) ? step : 0;
-        atomicAdd(&s_cnt[pos], delta);
+        if (k > last_key) return;                                       // beyond the last match: affects no position
+        atomicAdd(&s_cnt[dn < dlo ? 0 : lower_bound_in(k, dn)], delta);
     };
+    auto bin4 = [&](const float4 v, int g, int delta) { bin(v.x, g, delta); bin(v.y, g + 1, delta); bin(v.z, g + 2, delta); bin(v.w, g + 3, delta); };
     if (vec) {
         int g = tid * 4;
         for (; g + 3072 < ng; g += 4096) {                            // 4 independent 16-byte loads in flight
