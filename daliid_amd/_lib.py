@@ -26,6 +26,10 @@ _SIGNATURES = {
     "dali_ctx_create": [c_int, ctypes.POINTER(c_void_p)],
     "dali_ctx_destroy": [c_void_p],
     "dali_ctx_reserve": [c_void_p, c_size_t],
+    "dali_comm_unique_id": [c_void_p],
+    "dali_ctx_comm_init": [c_void_p, c_void_p, c_int, c_int],
+    "dali_ctx_comm_destroy": [c_void_p],
+    "dali_allreduce_bucket": [c_void_p, c_void_p, c_void_p, ctypes.c_int64],
     "dali_l2norm_rows": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "dali_l2norm_rows_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "dali_pairdist": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -17,6 +17,8 @@ struct dali_ctx {
     int num_cus;
     void* ws;          // grow-only device workspace
     size_t ws_bytes;
+    void* comm;        // RCCL communicator (ncclComm_t) of this process' rank, or null (dali_ctx_comm_init)
+    int comm_rank, comm_world;
 };
 
 namespace dali {

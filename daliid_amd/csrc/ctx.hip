@@ -55,12 +55,15 @@ extern "C" int dali_ctx_create(int device, dali_ctx** out) {
     c->num_cus = prop.multiProcessorCount;
     c->ws = nullptr;
     c->ws_bytes = 0;
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     *out = c;
     return DALI_OK;
 }
 
+extern "C" int dali_ctx_comm_destroy(dali_ctx* ctx);
 extern "C" int dali_ctx_destroy(dali_ctx* ctx) {
     if (!ctx) return DALI_OK;
+    (void)dali_ctx_comm_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     delete ctx;
     return DALI_OK;

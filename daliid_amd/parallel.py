@@ -10,6 +10,9 @@ DataParallel semantics, Encoders.py:88-89) and exchanges exactly
      layer3 7.1 M, layer2 1.2 M, layer1+stem 0.2 M floats), each launched on a side stream as soon as its stage is
      enqueued so it overlaps the remaining backward.  xGMI is a point-to-point mesh: few large buckets beat many small.
 Adam and the EMA then run redundantly on identical data on every rank (no weight broadcast, ever).
+
+The gradient buckets go either through ``torch.distributed`` (default) or, with ``DALIID_COMM=abi``, through the library's own RCCL
+communicator (``dali_allreduce_bucket``, include/daliid.h): torch.distributed then only carries the 128-byte unique id to the ranks.
 """
 import os
 
@@ -60,6 +63,31 @@ def allreduce_loss_stats(stats, group=None):
     return stats
 
 
+def use_abi_comm():
+    return os.environ.get("DALIID_COMM", "torch") == "abi"
+
+
+def init_abi_comm(device, group=None):
+    """Create this rank's RCCL communicator inside the library's context (once per process): rank 0 draws the unique id, the process
+    group's store carries it to the others.  -> the ctx handle."""
+    import ctypes
+    from . import _lib
+    c = _lib.ctx(device)
+    if getattr(init_abi_comm, "_done", None) == device.index:
+        return c
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [None]
+    if rank == 0:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().dali_comm_unique_id(buf), "dali_comm_unique_id")
+        box[0] = bytes(buf.raw)
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    idbuf = ctypes.create_string_buffer(box[0], 128)
+    _lib.check(_lib.lib().dali_ctx_comm_init(c, idbuf, rank, world), "dali_ctx_comm_init")
+    init_abi_comm._done = device.index
+    return c
+
+
 class GradReducer:
     """SUM all-reduce of the flat gradient buffer in per-stage buckets.  On CUDA the collectives run on a side stream
     behind an event recorded right after the stage's kernels were enqueued (overlap with the next stage's backward);
@@ -69,9 +97,12 @@ class GradReducer:
         self.flat, self.ranges, self.group = flat_grads, list(ranges), group
         self.cuda = flat_grads.is_cuda
         self.works = []
+        self.abi_ctx = None
         if self.cuda:
             self.stream = torch.cuda.Stream(device=flat_grads.device)
             self.ready = torch.cuda.Event()
+            if use_abi_comm():
+                self.abi_ctx = init_abi_comm(flat_grads.device, group)
 
     def reduce_stage(self, stage):
         b, e = self.ranges[stage]
@@ -83,7 +114,12 @@ class GradReducer:
         self.ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(self.ready)
-            self.works.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.abi_ctx is not None:
+                from . import _lib
+                _lib.check(_lib.lib().dali_allreduce_bucket(self.abi_ctx, _lib.c_void_p(self.stream.cuda_stream), _lib.ptr(self.flat[b:e]), e - b),
+                           "dali_allreduce_bucket")
+            else:
+                self.works.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         for w in self.works:

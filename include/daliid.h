@@ -253,6 +253,17 @@ int dali_proxy_loss_bwd(dali_ctx* ctx, void* stream, const int32_t* sel_idx, con
                         int D, const float* denom, float gscale, int accumulate, float* dfn);
 int dali_proxy_kmax(void);
 
+/* ---- data parallel: gradient all-reduce over RCCL (xGMI), one communicator per context = per process = per GPU --------------------
+ * Replaces nn.DataParallel's reduce of all gradients to GPU 0 (Encoders.py:39-40).  Rank 0 creates the 128-byte id
+ * (dali_comm_unique_id) and the host program hands it to the other ranks; every rank then calls dali_ctx_comm_init with the
+ * context's device current.  dali_allreduce_bucket: in-place SUM over all ranks of buf[0..count) fp32, enqueued on `stream`
+ * (reduce-scatter + all-gather when count divides by the world size, else ncclAllReduce).  RCCL is bound at run time: without it
+ * these return DALI_ERR_UNSUPPORTED and everything else works. */
+int dali_comm_unique_id(void* id128);
+int dali_ctx_comm_init(dali_ctx* ctx, const void* id128, int rank, int world);
+int dali_ctx_comm_destroy(dali_ctx* ctx);
+int dali_allreduce_bucket(dali_ctx* ctx, void* stream, float* buf, int64_t count);
+
 /* ---- optimizer side of the hot loop, on the flat fp32 storages ------------------------------------------- */
 /* torch.optim.Adam step (L2 weight decay added to the gradient; mainKIT.py:99, train_encodersKIT.py:214-216):
  * g' = grad_scale*g + wd*p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;

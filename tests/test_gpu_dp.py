@@ -126,13 +126,13 @@ def test_two_rank_train_steps_match_sharded_emulation(tmp_path):
     assert d < 2e-4, d            # Adam turns rounding-level gradient differences into <= lr-sized parameter differences
 
 
-def _rccl_worker(rank, world, port, out_dir):
+def _rccl_worker(rank, world, port, out_dir, comm="torch"):
     """backend "nccl" (= RCCL): one rank per GPU.  A one-GPU box can only host world size 1, which still runs every RCCL call
     of the step (communicator init, the 4-float loss-statistics all-reduce, the per-stage gradient all-reduces on the side
     stream with async work handles)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", DALIID_COMM=comm)
     import torch.distributed as dist
     from daliid_amd.losses import _codes
     from daliid_amd.train_encodersKIT import trainer
@@ -149,17 +149,21 @@ def _rccl_worker(rank, world, port, out_dir):
         stats = tr.train_step(heads, imgs.to(dev), _codes(labels, dev), sample_w(dist_lv, 10, 250, dev), acc)
     torch.cuda.synchronize()
     assert tr._dp is not None and dist.get_backend() == "nccl"
+    assert (tr._dp.abi_ctx is not None) == (comm == "abi")
     torch.save({"params": online.module.flat_params.cpu(), "stats": stats.cpu(), "grads": online.module.flat_grads.cpu()},
                os.path.join(out_dir, "rccl_rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_rccl_backend_runs_the_step_and_changes_nothing_at_world_size_1(tmp_path):
+@pytest.mark.parametrize("comm", ["torch", "abi"])
+def test_rccl_backend_runs_the_step_and_changes_nothing_at_world_size_1(tmp_path, comm):
+    """comm = "torch": gradient buckets through torch.distributed (backend nccl = RCCL); comm = "abi": through the library's own RCCL
+    communicator (dali_ctx_comm_init / dali_allreduce_bucket, include/daliid.h), torch.distributed only carrying the unique id."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     world = min(torch.cuda.device_count(), 2)
-    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path), comm), nprocs=world, join=True)
     outs = [torch.load(os.path.join(str(tmp_path), "rccl_rank%d.pt" % r)) for r in range(world)]
     for o in outs:
         assert torch.isfinite(o["params"]).all() and torch.isfinite(o["grads"]).all()
