@@ -331,7 +331,7 @@ def make_vit_state(args, world, rank, batch, device):
     from daliid_amd.ops_eval import l2norm_rows
     gen = torch.Generator(device=device).manual_seed(12 + rank)
     mk = lambda: V.ViTNeckNet(img_size=(224, 224), patch_size=16, stride_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
-                              drop_path_rate=0.0, device=device, seed=12)
+                              drop_path_rate=0.1, device=device, seed=12)        # the reference factory's default (vit_pytorch.py:453)
     online, momentum = mk(), mk()
     NC, D = 1024, 768
     centers = l2norm_rows(torch.randn(NC, D, device=device, generator=torch.Generator(device=device).manual_seed(1)))
@@ -411,7 +411,7 @@ def bench_train(args, world, rank):
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and not vit:
         cpu = cpu_baseline_train()
-    wl = ("configs[3]: TransReID ViT-B/16 bf16 224x224, batch %d per GPU, center+proxy heads, Adam, EMA" % batch) if vit else \
+    wl = ("configs[3]: TransReID ViT-B/16 bf16 224x224, drop_path 0.1, batch %d per GPU, center+proxy heads, Adam, EMA" % batch) if vit else \
          "configs[1]: ResNet-50 ReID bf16 256x128, PK batch 16x16=256 per GPU, center+proxy heads, Adam, EMA"
     return {"metric": "images/sec (train step)", "value": round(ips, 2), "unit": "images/s", "ms_per_step": round(ms_step, 3),
             "dtype": "bf16", "config": {"workload": wl + ("; data-parallel, RCCL all-reduce of gradients" if world > 1 else ""),

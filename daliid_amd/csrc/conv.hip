@@ -175,6 +175,20 @@ __device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, unsigned bits) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 1, 1) << 16;         // 0 or 0xffff0000
     return w & (lo | hi);
 }
+// exact-erf GELU (vit_pytorch.py:120-136, nn.GELU) and its derivative.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: three orders
+// below the bf16 rounding of the stored result) on v_rcp / v_exp: ocml's erff + expf were ~60 VALU instructions per element, a third of the
+// fc1 / fc2 epilogues' time.  cdf = Phi(v) = 0.5 (1 + erf(v / sqrt 2)), pdf = phi(v); both share exp(-v^2 / 2).
+__device__ __forceinline__ void gelu_parts(float v, float& cdf, float& pdf) {
+    const float z = fabsf(v) * 0.70710678118654752f;
+    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.44269504088896341f);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, v));
+    pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float v) { float c, p; gelu_parts(v, c, p); return v * c; }
+__device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
 // bit 0 / bit 1: the low / high bf16 half of w is > 0
 __device__ __forceinline__ unsigned pos_bits_bf16x2(uint32_t w) {
     return ((int)(int16_t)(w & 0xffffu) > 0 ? 1u : 0u) | (((int)w >> 16) > 0 ? 2u : 0u);
@@ -225,7 +239,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 5] = __builtin_amdgcn_s_memrealtime();     // stats done
 
     // ---- lean path: plain convolution (optionally + residual), interior tile, natural output addressing ----
-    const bool plain = LIN != 3 && !a.O2 && a.act == 0 && !a.dact_pre && !a.g.sub && (a.Cm & 7) == 0;      // bias (linear layers) is folded in below
+    const bool plain = LIN != 3 && !a.O2 && a.act == 0 && !a.dact_pre && !a.row_scale && !a.g.sub && (a.Cm & 7) == 0;   // bias (linear layers) is folded in below
     // the linear layers' GELU / pre-activation copy (O2) / GELU' factor take a second staged block further down, kept apart so that the
     // convolutions' path stays as lean as it was (folding them into one block cost the ResNet step 0.8 ms)
     // (only in the LIN instantiations of the kernels: compiled into every kernel it changed the convolutions' register allocation and
@@ -354,7 +368,12 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
                     if (a.act == 1) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = 0.5f * v[t] * (1.0f + erff(v[t] * 0.70710678118654752f));
+                        for (int t = 0; t < 4; ++t) v[t] = gelu_f(v[t]);
+                    }
+                    if (a.row_scale) {                          // DropPath: the whole branch output (bias included) times its sample's factor
+                        const float rs = a.row_scale[tn * TN + h * WROWS + wn * (FN_ * 16) + jj * 16 + (lane & 15)];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] *= rs;
                     }
                     if (in_tile) {
                         const uint2 rv = *slot;
@@ -365,7 +384,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                         } else {
 #pragma unroll
                             for (int t = 0; t < 4; ++t)
-                                v[t] *= 0.5f * (1.0f + erff(x4[t] * 0.70710678118654752f)) + x4[t] * 0.3989422804014327f * expf(-0.5f * x4[t] * x4[t]);
+                                v[t] *= gelu_grad_f(x4[t]);
                         }
                     }
                     *slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
@@ -492,7 +511,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 if (a.O2) *reinterpret_cast<uint2*>(a.O2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 if (a.act == 1) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = 0.5f * v[t] * (1.0f + erff(v[t] * 0.70710678118654752f));
+                    for (int t = 0; t < 4; ++t) v[t] = gelu_f(v[t]);
                 }
                 if (a.dact_pre) {
                     const uint2 pv = *reinterpret_cast<const uint2*>(a.dact_pre + o);
@@ -500,7 +519,12 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                                          bf16_bits_to_f32(pv.y >> 16)};
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        v[t] *= 0.5f * (1.0f + erff(x4[t] * 0.70710678118654752f)) + x4[t] * 0.3989422804014327f * expf(-0.5f * x4[t] * x4[t]);
+                        v[t] *= gelu_grad_f(x4[t]);
+                }
+                if (a.row_scale) {
+                    const float rs = a.row_scale[p];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] *= rs;
                 }
                 }
                 if (a.Res) {
@@ -2026,7 +2050,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     // k-tile 64 pays where the main loop dominates (K >= 1024); with a short K or the 128 x 128 tile the smaller k-tile's 2-3
     // co-resident workgroups overlap their epilogues better (measured per layer: 256 x 256 -12..-15 %; 128 x 256 wave-specialised
     // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
-    const bool lin = a.act != 0 || a.O2 != nullptr || a.dact_pre != nullptr;      // linear-layer epilogue extras: the LIN kernel instantiations
+    const bool lin = a.act != 0 || a.O2 != nullptr || a.dact_pre != nullptr || a.row_scale != nullptr;      // linear-layer epilogue extras: the LIN kernel instantiations
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
     const int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
     static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
@@ -2378,9 +2402,9 @@ static void linear_geom(GatherGeom& g, int K) {
 }
 namespace dali {
 int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,
-                      uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N) {
+                      uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N, const float* row_scale) {
     IGemmArgs a{};
-    a.W = w; a.X = x; a.O = y; a.Res = residual; a.bias = bias; a.act = act; a.O2 = pre; a.dact_pre = dact_pre;
+    a.W = w; a.X = x; a.O = y; a.Res = residual; a.bias = bias; a.act = act; a.O2 = pre; a.dact_pre = dact_pre; a.row_scale = row_scale;
     a.Cm = N; a.P = rows;
     linear_geom(a.g, K);
     return launch_igemm_conv(st, a);

@@ -42,6 +42,8 @@ struct IGemmArgs {
     // Forward: the BatchNorm of a 1x1 convolution whose batch statistics were derived from the Gram matrix of its input BEFORE the
     // GEMM ran (bnlin.hip), so that y = relu(bn(conv(x)) + identity) leaves the GEMM directly and the raw conv output is never stored.
     // Backward: out_mask = ReLU mask of the block output this gradient belongs to, so that dz = dy * (y > 0) is what is stored.
+    const float* row_scale;   // optional [P] (linear layers, LIN instantiations): value = row_scale[p] * (acc + bias) before the residual is added:
+                              // DropPath of a residual branch, vit_pytorch.py:45-62 (the caller expands the per-sample factors to rows)
     const float* out_scale;   // [Cm]
     const float* out_shift;   // [Cm]
     int out_relu;
@@ -82,7 +84,7 @@ bool wgrad_colsum_supported(int Cm, int Ntot, int taps, int P);
 int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate);
 
 int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,
-                      uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N);
+                      uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N, const float* row_scale = nullptr);
 int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab);
 size_t linear_wgrad_slab_bytes(int rows, int K, int N);
 
@@ -151,6 +153,7 @@ int launch_colsum_partials(hipStream_t st, const uint16_t* y, int rows, int C, f
 // out = (res or 0) + scale[row / rows_per_sample] * branch   (DropPath per sample; C % 8 == 0)
 int launch_rowscale_add(hipStream_t st, const uint16_t* branch, const float* scale, int samples, int rows_per_sample, int C, const uint16_t* res,
                         uint16_t* out);
+int launch_expand_rowscale(hipStream_t st, const float* scale, int n_vec, int B, int T, float* out);
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse);
 int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
                          float scale, uint16_t* dqkv);

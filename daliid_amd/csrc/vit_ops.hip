@@ -571,6 +571,12 @@ __global__ __launch_bounds__(256) void rowscale_add_kernel(const uint16_t* __res
     }
 }
 
+// per-sample DropPath factors [n_vec][B] -> per-row factors [n_vec][B * T] (what the linear epilogues index by output row)
+__global__ __launch_bounds__(256) void expand_rowscale_kernel(const float* __restrict__ scale, int n_vec, int B, int T, float* __restrict__ out) {
+    const size_t total = (size_t)n_vec * B * T;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) out[i] = scale[i / T];
+}
+
 static inline int vgrid(size_t items, int cap = 16384) {
     size_t b = (items + 255) / 256;
     if (b > (size_t)cap) b = cap;
@@ -591,6 +597,11 @@ int launch_assemble_tokens(hipStream_t st, const uint16_t* pe, const float* cls,
 }
 int launch_assemble_tokens_bwd(hipStream_t st, const uint16_t* dx, int B, int T, int C, float* dpos, float* dcls, uint16_t* dpe) {
     hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3((T * (C / 8) + 255) / 256), dim3(256), 0, st, dx, B, T, C, dpos, dcls, dpe);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_expand_rowscale(hipStream_t st, const float* scale, int n_vec, int B, int T, float* out) {
+    hipLaunchKernelGGL(expand_rowscale_kernel, dim3(vgrid((size_t)n_vec * B * T, 2048)), dim3(256), 0, st, scale, n_vec, B, T, out);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }

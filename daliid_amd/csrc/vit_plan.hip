@@ -39,7 +39,7 @@ struct dali_vit {
     std::vector<std::pair<void**, size_t>> fixups;
     uint16_t *wbf16 = nullptr, *patches = nullptr, *pe = nullptr, *x0 = nullptr, *cls_rows = nullptr, *dcls_rows = nullptr, *dgf16 = nullptr;
     float *gf = nullptr, *dgf = nullptr, *neck_mean = nullptr, *neck_invstd = nullptr, *slab = nullptr, *partial = nullptr;
-    float *fin_mean = nullptr, *fin_rstd = nullptr;
+    float *fin_mean = nullptr, *fin_rstd = nullptr, *dp_rows = nullptr;        // dp_rows [2*depth][rows]: DropPath factors per output row
     double* scratch = nullptr;
     uint16_t* gbuf[4] = {nullptr, nullptr, nullptr, nullptr};
     float *P = nullptr, *G = nullptr, *Bf = nullptr;
@@ -141,6 +141,7 @@ extern "C" int dali_vit_create(dali_ctx* ctx, const dali_vit_cfg* cfg, dali_vit*
     rsv(n, a, n->neck_mean, C * 4); rsv(n, a, n->neck_invstd, C * 4);
     rsv(n, a, n->fin_mean, n->B * 4); rsv(n, a, n->fin_rstd, n->B * 4);
     rsv(n, a, n->slab, slab); rsv(n, a, n->partial, part);
+    rsv(n, a, n->dp_rows, (size_t)2 * cfg->depth * rows * 4);
     rsv(n, a, n->scratch, reduce_scratch_bytes((int)std::max<size_t>(Hd, 3 * C), 2));
     for (int i = 0; i < 4; ++i) rsv(n, a, n->gbuf[i], rows * std::max<size_t>(Hd, 3 * C) * 2);
     n->arena_bytes = a.used;
@@ -206,24 +207,20 @@ extern "C" int dali_vit_forward(dali_vit* n, void* stream, const float* images, 
     const uint16_t* x = n->x0;
     const float* dp = training ? n->dp_scale : nullptr;        // DropPath is the identity in eval mode (vit_pytorch.py:58)
     n->dp_used = dp;
+    if (dp && (rc = launch_expand_rowscale(st, dp, 2 * (int)n->blocks.size(), n->B, n->T, n->dp_rows))) return rc;
     for (int bi = 0; bi < (int)n->blocks.size(); ++bi) {
         VBlock& b = n->blocks[bi];
         b.x_in = const_cast<uint16_t*>(x);
         if ((rc = launch_layernorm_fwd(st, x, n->P + b.n1.g_off, n->P + b.n1.b_off, rows, C, eps, b.h1, b.n1.mean, b.n1.rstd, nullptr))) return rc;
         if ((rc = launch_linear_fwd(st, b.h1, b.qkv.w, n->P + b.qkv.b_off, 0, nullptr, b.qkv_o, nullptr, nullptr, rows, C, 3 * C))) return rc;
         if ((rc = launch_attention_fwd(st, b.qkv_o, n->B, n->T, n->H, scale, b.att, b.lse))) return rc;
-        const float* s_att = dp ? dp + (size_t)(2 * bi) * n->B : nullptr;
-        const float* s_mlp = dp ? dp + (size_t)(2 * bi + 1) * n->B : nullptr;
-        if (dp) {          // x_mid = x + s[b] * proj(...): the branch goes to scratch, the scaled add is its own pass
-            if ((rc = launch_linear_fwd(st, b.att, b.proj.w, n->P + b.proj.b_off, 0, nullptr, n->gbuf[1], nullptr, nullptr, rows, C, C))) return rc;
-            if ((rc = launch_rowscale_add(st, n->gbuf[1], s_att, n->B, n->T, C, x, b.x_mid))) return rc;
-        } else if ((rc = launch_linear_fwd(st, b.att, b.proj.w, n->P + b.proj.b_off, 0, x, b.x_mid, nullptr, nullptr, rows, C, C))) return rc;
+        // x_mid = x + s[b] * proj(...): the per-row factor rides in the GEMM's epilogue (IGemmArgs::row_scale)
+        if ((rc = launch_linear_fwd(st, b.att, b.proj.w, n->P + b.proj.b_off, 0, x, b.x_mid, nullptr, nullptr, rows, C, C,
+                                    dp ? n->dp_rows + (size_t)(2 * bi) * rows : nullptr))) return rc;
         if ((rc = launch_layernorm_fwd(st, b.x_mid, n->P + b.n2.g_off, n->P + b.n2.b_off, rows, C, eps, b.h2, b.n2.mean, b.n2.rstd, nullptr))) return rc;
         if ((rc = launch_linear_fwd(st, b.h2, b.fc1.w, n->P + b.fc1.b_off, 1, nullptr, b.act1, b.pre1, nullptr, rows, C, Hd))) return rc;
-        if (dp) {
-            if ((rc = launch_linear_fwd(st, b.act1, b.fc2.w, n->P + b.fc2.b_off, 0, nullptr, n->gbuf[1], nullptr, nullptr, rows, Hd, C))) return rc;
-            if ((rc = launch_rowscale_add(st, n->gbuf[1], s_mlp, n->B, n->T, C, b.x_mid, b.x_out))) return rc;
-        } else if ((rc = launch_linear_fwd(st, b.act1, b.fc2.w, n->P + b.fc2.b_off, 0, b.x_mid, b.x_out, nullptr, nullptr, rows, Hd, C))) return rc;
+        if ((rc = launch_linear_fwd(st, b.act1, b.fc2.w, n->P + b.fc2.b_off, 0, b.x_mid, b.x_out, nullptr, nullptr, rows, Hd, C,
+                                    dp ? n->dp_rows + (size_t)(2 * bi + 1) * rows : nullptr))) return rc;
         x = b.x_out;
     }
     // final LayerNorm on the cls rows only (x[:, 0], vit_pytorch.py:401-403), then the BN neck (make_models.py:187)
