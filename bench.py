@@ -331,7 +331,7 @@ def make_vit_state(args, world, rank, batch, device):
     from daliid_amd.ops_eval import l2norm_rows
     gen = torch.Generator(device=device).manual_seed(12 + rank)
     mk = lambda: V.ViTNeckNet(img_size=(224, 224), patch_size=16, stride_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
-                              drop_path_rate=0.1, device=device, seed=12)        # the reference factory's default (vit_pytorch.py:453)
+                              drop_path_rate=float(os.environ.get("DALIID_BENCH_DROP_PATH", "0.1")), device=device, seed=12)   # 0.1: the reference factory's default (vit_pytorch.py:453)
     online, momentum = mk(), mk()
     NC, D = 1024, 768
     centers = l2norm_rows(torch.randn(NC, D, device=device, generator=torch.Generator(device=device).manual_seed(1)))

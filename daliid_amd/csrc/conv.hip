@@ -2116,8 +2116,14 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         // workgroup per CU: 122 / 118)
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
         const int lds = (64 + 256) * 64 * 2 * 2;
-        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
-        hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        static int narrow_np = -1;                         // DALI_NARROW_NP (A/B aid): producer waves of the narrow k-tile-64 kernel
+        if (narrow_np < 0) { const char* e = getenv("DALI_NARROW_NP"); narrow_np = e ? atoi(e) : 4; }
+        DALI_ONCE_PER_DEVICE({
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        });
+        if (narrow_np == 8) hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 8, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(768), lds, st, args, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
