@@ -461,8 +461,14 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
                     if (a.Res) {
                         const uint2 rv = *slot;
-                        v0 += bf16_bits_to_f32(rv.x & 0xffffu); v1 += bf16_bits_to_f32(rv.x >> 16);
-                        v2 += bf16_bits_to_f32(rv.y & 0xffffu); v3 += bf16_bits_to_f32(rv.y >> 16);
+                        if (a.res_scale) {                      // (loaded per use: L1-resident, and no registers held across the tile)
+                            const float4 rs = *reinterpret_cast<const float4*>(a.res_scale + tm * TM + mb + i * 16);
+                            v0 += rs.x * bf16_bits_to_f32(rv.x & 0xffffu); v1 += rs.y * bf16_bits_to_f32(rv.x >> 16);
+                            v2 += rs.z * bf16_bits_to_f32(rv.y & 0xffffu); v3 += rs.w * bf16_bits_to_f32(rv.y >> 16);
+                        } else {
+                            v0 += bf16_bits_to_f32(rv.x & 0xffffu); v1 += bf16_bits_to_f32(rv.x >> 16);
+                            v2 += bf16_bits_to_f32(rv.y & 0xffffu); v3 += bf16_bits_to_f32(rv.y >> 16);
+                        }
                     }
                     if (a.out_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                     *slot = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
@@ -533,8 +539,12 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                         const unsigned m = a.res_mask[o >> 3] >> (o & 4);
                         rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2);
                     }
-                    v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
-                    v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                    float r4[4] = {bf16_bits_to_f32(rv.x & 0xffffu), bf16_bits_to_f32(rv.x >> 16), bf16_bits_to_f32(rv.y & 0xffffu), bf16_bits_to_f32(rv.y >> 16)};
+                    if constexpr (LIN == 3) if (a.res_scale) {
+                        const float4 rs = *reinterpret_cast<const float4*>(a.res_scale + c);
+                        r4[0] *= rs.x; r4[1] *= rs.y; r4[2] *= rs.z; r4[3] *= rs.w;
+                    }
+                    v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
                 }
                 uint2 ov = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 if constexpr (LIN == 3) {
@@ -2058,7 +2068,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     if ((k64 == 2 || k64 == 6) && !(K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
     // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
     // instantiations compile none of it (code that is never executed still cost their register allocation 0.4-0.8 ms per step)
-    const bool fused = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask;
+    const bool fused = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;
     if (fused) {
         if (in_bn || !dma_ok || (a.Cm & 7) || lin) {
             set_error("conv: the fused output stage needs Cm %% 8 == 0, tensors below 2 GiB, no operand transform and no linear-layer extras");
@@ -2391,12 +2401,12 @@ extern "C" int dali_conv2d_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
 // bits_out = (y > 0).  mode 0: forward (w [cout][cin]); mode 1: data gradient (w = the [cin][cout] image, x = dy).
 extern "C" int dali_conv1x1_fused(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y, int pixels, int cin, int cout,
                                   const float* out_scale, const float* out_shift, const float* bias, const uint16_t* residual, int out_relu,
-                                  uint8_t* bits_out, const uint8_t* out_mask) {
+                                  uint8_t* bits_out, const uint8_t* out_mask, const float* res_scale) {
     DALI_REQUIRE(ctx && x && w && y, "dali_conv1x1_fused: null argument");
     DALI_REQUIRE(cin % 32 == 0 && cout % 8 == 0 && pixels > 0, "dali_conv1x1_fused: cin %% 32, cout %% 8 (cin=%d cout=%d)", cin, cout);
     IGemmArgs a{};
     a.W = w; a.X = x; a.O = y; a.Res = residual; a.bias = bias;
-    a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu; a.bits_out = bits_out; a.out_mask = out_mask;
+    a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu; a.bits_out = bits_out; a.out_mask = out_mask; a.res_scale = res_scale;
     a.Cm = cout; a.P = pixels;
     fill_geom(a.g, 1, 1, pixels, cin, 1, pixels, 1, 1, 1, 0, 0);
     return launch_igemm_conv((hipStream_t)stream, a);

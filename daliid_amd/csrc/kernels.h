@@ -44,6 +44,8 @@ struct IGemmArgs {
     // Backward: out_mask = ReLU mask of the block output this gradient belongs to, so that dz = dy * (y > 0) is what is stored.
     const float* row_scale;   // optional [P] (linear layers, LIN instantiations): value = row_scale[p] * (acc + bias) before the residual is added:
                               // DropPath of a residual branch, vit_pytorch.py:45-62 (the caller expands the per-sample factors to rows)
+    const float* res_scale;   // optional [Cm] (fused output stage): the residual enters as res_scale[c] * Res (the downsample branch's BatchNorm scale;
+                              // its shift rides in `bias`)
     const float* out_scale;   // [Cm]
     const float* out_shift;   // [Cm]
     int out_relu;

@@ -215,7 +215,9 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
                 add_bn(net, b.bd, pre + ".downsample.1", planes * 4);
             }
             b.hout = b.c2.hout; b.wout = b.c2.wout;
-            b.lin3 = !b.has_ds && bnlin_on() && planes % 32 == 0 && planes <= bnlin_max_width();
+            // bn3 through the moments of a2 (bnlin.hip); in a block with a downsample branch the identity enters conv3's epilogue as
+            // scale_d * rawd + shift_d (res_scale / bias) and the downsample BatchNorm keeps its own two-pass backward
+            b.lin3 = bnlin_on() && planes % 32 == 0 && planes <= bnlin_max_width();
             h = b.hout; w = b.wout; inpl = planes * 4;
             net->blocks.push_back(b);
         }
@@ -486,6 +488,10 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
             } else if ((rc = bn_eval(net, st, b.b3))) return rc;
             IGemmArgs a{};
             a.W = b.c3.w_bf16; a.X = b.a2; a.O = b.y; a.Res = x; a.out_scale = b.b3.scale; a.out_shift = b.b3.shift; a.out_relu = 1;
+            if (b.has_ds) {                               // identity = bnd(convd(x)): raw output + its BatchNorm as residual scale / extra shift
+                if ((rc = conv_bn_fwd(net, st, b.cd, b.bd, x, nullptr, b.rawd, tr))) return rc;
+                a.Res = b.rawd; a.res_scale = b.bd.scale; a.bias = b.bd.shift;
+            }
             a.bits_out = tr ? b.ybits : nullptr;
             a.Cm = b.cout; a.P = Pout; a.g = conv_geom(b.c3, 0);
             if ((rc = launch_igemm_conv(st, a))) return rc;
@@ -535,6 +541,12 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         if ((rc = conv_dgrad(net, st, b.c3, dz, nullptr, d_a2, nullptr, b.wd1, b.bvec))) return rc;             // dz (A.W3) + W3^T Kc
         const Conv sq = square_conv(b.c3);
         if ((rc = conv_dgrad(net, st, sq, b.a2, d_a2, d_a2, nullptr, b.wd2, nullptr))) return rc;               // - a2 (W3^T diag(Q) W3), in place
+        if (b.has_ds) {                                           // the downsample BatchNorm: its own two passes over (dz, rawd)
+            d_rawd = next_gbuf(net, dz, d_a2, scratch_a);
+            BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
+            if ((rc = launch_bn_bwd(st, dz, nullptr, nullptr, sd, nullptr, 0, Pout, b.cout, net->bwd_partial, b.bd.coef, nullptr, net->G + b.bd.g_off,
+                                    net->G + b.bd.b_off, nullptr, nullptr, d_rawd, nullptr, nullptr, net->red_scratch))) return rc;
+        }
     } else {
         uint16_t* d_raw3 = next_gbuf(net, dz);
         d_rawd = b.has_ds ? next_gbuf(net, dz, d_raw3) : nullptr;

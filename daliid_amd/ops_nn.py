@@ -61,7 +61,8 @@ def conv2d_wgrad(x, dy, rs, stride=1, pad=0, in_scale=None, in_shift=None, in_re
     return out
 
 
-def conv1x1_fused(x, w, out_scale=None, out_shift=None, bias=None, residual=None, relu=False, want_bits=False, out_mask=None, inplace=False):
+def conv1x1_fused(x, w, out_scale=None, out_shift=None, bias=None, residual=None, relu=False, want_bits=False, out_mask=None, inplace=False,
+                  res_scale=None):
     """x [P,cin] bf16, w [cout,cin] bf16 -> y [P,cout] = gate(relu?(acc*scale + shift + bias + residual)) (, bits uint8 [P*cout/8])."""
     P, cin = x.shape
     cout = w.shape[0]
@@ -69,7 +70,7 @@ def conv1x1_fused(x, w, out_scale=None, out_shift=None, bias=None, residual=None
     bits = torch.empty(P * cout // 8, device=x.device, dtype=torch.uint8) if want_bits else None
     _lib.check(_lib.lib().dali_conv1x1_fused(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16, "x"), _lib.ptr(w, bf16, "w"), _lib.ptr(y),
                                               P, cin, cout, _lib.ptr(out_scale), _lib.ptr(out_shift), _lib.ptr(bias), _lib.ptr(residual), int(relu),
-                                              _lib.ptr(bits), _lib.ptr(out_mask, torch.uint8, "out_mask")), "dali_conv1x1_fused")
+                                              _lib.ptr(bits), _lib.ptr(out_mask, torch.uint8, "out_mask"), _lib.ptr(res_scale)), "dali_conv1x1_fused")
     return (y, bits) if want_bits else y
 
 

@@ -123,13 +123,14 @@ int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16
                     int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
                     const float* in_scale, const float* in_shift, int in_relu, float* stats);
 /* 1x1 convolution (a [pixels][cin] x [cout][cin]^T GEMM) with the fused output stage:
- *   y = gate_{out_mask}( relu?( acc * out_scale[c] + out_shift[c] + bias[c] + residual ) ),  bits_out = (y > 0), 1 bit per element.
+ *   y = gate_{out_mask}( relu?( acc * out_scale[c] + out_shift[c] + bias[c] + res_scale[c] * residual ) ),  bits_out = (y > 0), 1 bit per
+ *   element (res_scale: the downsample branch's BatchNorm scale when the residual is its raw convolution output).
  * Forward use: bn3 + identity + ReLU of a bottleneck inside conv3 (Encoders.py:330-339 over torchvision's Bottleneck), with the batch
  * statistics from dali_bnlin_fwd.  Backward use: the masked gradient dz = dy * (y > 0) leaves the data-gradient GEMM directly.
  * Every pointer after `cout` is nullable; cin % 32 == 0, cout % 8 == 0. */
 int dali_conv1x1_fused(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y, int pixels, int cin, int cout,
                        const float* out_scale, const float* out_shift, const float* bias, const uint16_t* residual, int out_relu,
-                       uint8_t* bits_out, const uint8_t* out_mask);
+                       uint8_t* bits_out, const uint8_t* out_mask, const float* res_scale);
 /* Training-mode BatchNorm behind a 1x1 convolution WITHOUT the convolution's output (csrc/bnlin.hip): raw = a W^T is linear in
  * a [P][w] (bf16), so its batch statistics follow from gram = a^T a [w][w] and m2 = colsum(a) [w] (returned, fp32):
  * mean = W m2 / P, E[raw^2] = diag(W gram W^T) / P; ut = (W gram)^T [w][C] (fp32) is returned for the backward, with m2.  Outputs scale = gamma*invstd, shift = beta - mean*scale,

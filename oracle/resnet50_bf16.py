@@ -60,9 +60,9 @@ def _bn_train(u, uq, bn, eps=1e-5):
 
 def stores_raw3(blk):
     """Does the HIP plan store conv3's output of this bottleneck in bf16?  Not where bn3 runs through the moments of a2 (csrc/bnlin.hip):
-    blocks without a downsample branch whose width is a multiple of 32 and at most DALI_BNLIN_MAXW (default 128; resnet_plan.hip)."""
+    blocks whose width is a multiple of 32 and at most DALI_BNLIN_MAXW (default 128; resnet_plan.hip)."""
     import os
-    if blk.downsample is not None or os.environ.get("DALI_BNLIN", "1") == "0":
+    if os.environ.get("DALI_BNLIN", "1") == "0":
         return True
     w = blk.conv3.in_channels
     return not (w % 32 == 0 and w <= int(os.environ.get("DALI_BNLIN_MAXW", "128")))

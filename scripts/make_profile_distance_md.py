@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_distance/ (from scripts/profile_distance.sh) -> profiles/r01_distance_kernel_stats.{md,csv}."""
-import csv, shutil
+import csv, os, shutil
+RND = os.environ.get("ROUND", "r02")
 src = "gpurun_out/prof_distance"
-shutil.copy(src + "/kernel_stats.csv", "profiles/r01_distance_kernel_stats.csv")
+shutil.copy(src + "/kernel_stats.csv", "profiles/%s_distance_kernel_stats.csv" % RND)
 last = lambda f: open(src + "/" + f).read().strip().splitlines()[-1]
 rows = list(csv.DictReader(open(src + "/kernel_stats.csv")))
-out = ["# Round 1 -- gallery distance (configs[4]) kernel profile\n",
+out = ["# Round %s -- gallery distance (configs[4]) kernel profile\n" % RND[1:].lstrip("0"),
        "Produced by `bash scripts/profile_distance.sh` on an MI355X box: `python bench.py --workload distance --steps 5 --warmup 2` (unprofiled, with the CPU "
        "baseline), the same with `--precision bf16`, `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload distance --steps 5 "
        "--warmup 2 --no-cpu-baseline`, `python scripts/time_rank.py`; summary by `scripts/make_profile_distance_md.py`.\n",
@@ -25,5 +26,5 @@ try:
                "`scripts/effective_clock.py`: GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time; the 2.5 PFLOP/s dense bf16 peak is quoted at 2.4 GHz):\n\n```\n%s\n```\n" % clk)
 except OSError:
     pass
-open("profiles/r01_distance_kernel_stats.md", "w").write("\n".join(out) + "\n")
-print("wrote profiles/r01_distance_kernel_stats.md")
+open("profiles/%s_distance_kernel_stats.md" % RND, "w").write("\n".join(out) + "\n")
+print("wrote profiles/%s_distance_kernel_stats.md" % RND)

@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_<wl>/ (from scripts/profile_train.sh) -> profiles/r01_<wl>_* (committed summary)."""
-import csv, json, shutil, sys
+"""gpurun_out/prof_<wl>/ (from scripts/profile_train.sh) -> profiles/<ROUND>_<wl>_* (committed summary)."""
+import csv, json, os, shutil, sys
+RND = os.environ.get("ROUND", "r02")
 wl = sys.argv[1] if len(sys.argv) > 1 else "train"
 src, name = "gpurun_out/prof_%s" % wl, {"train": "train_step", "vit": "vit_step"}[wl]
-shutil.copy(src + "/pmc_traffic.json", "profiles/r01_%s_pmc_traffic.json" % wl)
-shutil.copy(src + "/kernel_stats.csv", "profiles/r01_%s_kernel_stats.csv" % name)
+shutil.copy(src + "/pmc_traffic.json", "profiles/%s_%s_pmc_traffic.json" % (RND, wl))
+shutil.copy(src + "/kernel_stats.csv", "profiles/%s_%s_kernel_stats.csv" % (RND, name))
 rows = list(csv.DictReader(open(src + "/kernel_stats.csv")))
 bench = open(src + "/bench_prof.json").read().strip().splitlines()[-1]
 bench_full = open(src + "/bench.json").read().strip().splitlines()[-1]
 pmc = json.load(open(src + "/pmc_traffic.json"))
 pmd = open(src + "/pmc_traffic.md").read()
 steps = 16
-out = ["# Round 1 -- %s kernel profile\n" % name.replace("_", " ")]
+out = ["# Round %s -- %s kernel profile\n" % (RND[1:].lstrip("0"), name.replace("_", " "))]
 out.append("Produced by `bash scripts/profile_train.sh %s` on an MI355X box: (1) plain `python bench.py --workload %s --steps 10 --warmup 3`, "
            "(2) `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload %s --steps 10 --warmup 3 --no-cpu-baseline`, "
-           "(3)+(4) `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run, `-- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; "
+           "(3)+(4) `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run, `-- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-distance` "
+           "(passes 2-4 run with `--no-distance`; pass 1 is the driver's default command); "
            "summary by `scripts/make_profile_md.py`.\n" % (wl, wl, wl))
 out.append("Bench line of run (1) (unprofiled):\n\n```\n%s\n```\n" % bench_full)
 out.append("Bench line of run (2) (under rocprofv3):\n\n```\n%s\n```\n" % bench)
@@ -39,5 +41,5 @@ out.append("Corrections: %s.\n" % pmc["corrections"])
 out.append("```\n%s\n```\n" % json.dumps(pmc["per_family_bytes_per_step"], indent=1))
 out.append("All kernels: %.1f GB/step; GEMM kernels %.1f GB/step.\n" % (pmc["all_kernels_hbm_bytes_per_step"] / 1e9, pmc["gemm_kernels_hbm_bytes_per_step"] / 1e9))
 out.append(pmd)
-open("profiles/r01_%s_kernel_stats.md" % name, "w").write("\n".join(out))
-print("wrote profiles/r01_%s_kernel_stats.md" % name)
+open("profiles/%s_%s_kernel_stats.md" % (RND, name), "w").write("\n".join(out))
+print("wrote profiles/%s_%s_kernel_stats.md" % (RND, name))

@@ -6,7 +6,17 @@ into HBM bytes per train step, per kernel family.
 
 Corrections (guide, "HBM" section): rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests
 of wide (16 B/lane) streaming reads at 64 B, so reads are doubled; WRITE_SIZE is exact for 16 B/lane streaming stores."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, hashlib, json, os, sys
+
+
+def kernel_source_hash():
+    """the same hash bench.py computes: ties this profile to the kernel sources it was measured on"""
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "daliid_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(d, counter):
@@ -24,9 +34,11 @@ def load(d, counter):
 def family(name):
     if "igemm_conv" in name or "igemm_wgrad" in name:
         return "gemm"
+    if "bnlin" in name:
+        return "bnlin_small_products"                 # csrc/bnlin.hip: the w^2-sized products / statistics of the Gram scheme
     if "bn_" in name or "maxpool" in name or "head_pool" in name or "bn1d" in name:
         return "batchnorm_pool"
-    if "splitk" in name or "reduce_partials" in name:
+    if "splitk" in name or "reduce_partials" in name or "colsum" in name or "finish_sum" in name:
         return "reductions"
     return "other"
 
@@ -43,7 +55,7 @@ def main():
         f = family(k)
         fam[f][0] += rd; fam[f][1] += wr; fam[f][2] += n
         rows.append((rd + wr, k, rd, wr, n))
-    res = {"steps_in_process": steps,
+    res = {"steps_in_process": steps, "kernel_source_hash": kernel_source_hash(),
            "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE KiB x1024",
            "gemm_kernels_hbm_bytes_per_step": round((fam["gemm"][0] + fam["gemm"][1]) / steps),
            "per_family_bytes_per_step": {f: {"read": round(v[0] / steps), "write": round(v[1] / steps), "launches": v[2] // steps}

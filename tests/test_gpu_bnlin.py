@@ -50,6 +50,11 @@ def test_conv1x1_fused_forward_stage(nn, P, cin, cout):
     # no residual, no relu: a plain affine of the accumulators
     y2 = nn.conv1x1_fused(x, w, out_scale=scale, out_shift=shift)
     ulp_close(y2, acc * scale + shift, 1.5)
+    # the residual as another BatchNorm's raw input: res_scale * residual + bias (a bottleneck with a downsample branch)
+    rs, rb = (0.5 + torch.rand(cout, generator=g)).cuda(), (0.3 * torch.randn(cout, generator=g)).cuda()
+    y3, bits3 = nn.conv1x1_fused(x, w, out_scale=scale, out_shift=shift, bias=rb, residual=res, res_scale=rs, relu=True, want_bits=True)
+    ulp_close(y3, torch.relu(acc * scale + shift + rb + rs * res.float()), 1.5)
+    assert torch.equal(bits3, bits_of(y3))
 
 
 @pytest.mark.parametrize("P,cin,cout", [(4096, 64, 256), (300, 32, 136), (32768, 512, 2048), (32768, 2048, 1024)])
