@@ -158,6 +158,12 @@ int bnlin_max_width() {
     if (v == -1) { const char* e = getenv("DALI_BNLIN_MAXW"); v = e ? atoi(e) : 128; }
     return v;
 }
+// DALI_BNLIN_DS=0 (A/B aid): blocks with a downsample branch keep the materialised form
+bool bnlin_ds() {
+    static int v = -1;
+    if (v == -1) { const char* e = getenv("DALI_BNLIN_DS"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 // a cin = cout = w 1x1 convolution on the grid of conv3: the shape of the Gram GEMM a2^T a2 and of the second data-gradient GEMM
 Conv square_conv(const Conv& c3) {
     Conv q = c3;
@@ -217,7 +223,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             b.hout = b.c2.hout; b.wout = b.c2.wout;
             // bn3 through the moments of a2 (bnlin.hip); in a block with a downsample branch the identity enters conv3's epilogue as
             // scale_d * rawd + shift_d (res_scale / bias) and the downsample BatchNorm keeps its own two-pass backward
-            b.lin3 = bnlin_on() && planes % 32 == 0 && planes <= bnlin_max_width();
+            b.lin3 = bnlin_on() && planes % 32 == 0 && planes <= bnlin_max_width() && (!b.has_ds || bnlin_ds());
             h = b.hout; w = b.wout; inpl = planes * 4;
             net->blocks.push_back(b);
         }
