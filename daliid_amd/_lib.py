@@ -58,6 +58,7 @@ _SIGNATURES = {
                       c_void_p, c_void_p, c_void_p],
     "dali_bn1d_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6,
     "dali_linear_fwd": [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int] * 3,
+    "dali_linear_fwd_scaled": [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int] * 3,
     "dali_linear_dgrad": [c_void_p] * 7 + [c_int] * 3,
     "dali_linear_wgrad": [c_void_p] * 6 + [c_int] * 3,
     "dali_vit_patchify": [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],

@@ -189,17 +189,98 @@ __device__ __forceinline__ void gelu_parts(float v, float& cdf, float& pdf) {
 }
 __device__ __forceinline__ float gelu_f(float v) { float c, p; gelu_parts(v, c, p); return v * c; }
 __device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
+__device__ __forceinline__ void unpack8(const uint4& q, float (&f)[8]) {
+    f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = bf16_bits_to_f32(q.x >> 16); f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = bf16_bits_to_f32(q.y >> 16);
+    f[4] = bf16_bits_to_f32(q.z & 0xffffu); f[5] = bf16_bits_to_f32(q.z >> 16); f[6] = bf16_bits_to_f32(q.w & 0xffffu); f[7] = bf16_bits_to_f32(q.w >> 16);
+}
 // bit 0 / bit 1: the low / high bf16 half of w is > 0
 __device__ __forceinline__ unsigned pos_bits_bf16x2(uint32_t w) {
     return ((int)(int16_t)(w & 0xffffu) > 0 ? 1u : 0u) | (((int)w >> 16) > 0 ? 2u : 0u);
 }
+// Staged store, one 16-pixel column block of every wave at a time (any FN; used by the 256 x 320 tile, FN = 5).  The staging is a pure
+// transpose: the WNW * 16 pixels of step j go through LDS as [pixel][TM channels] fp32 accumulators, and the thread that reads 8 adjacent
+// channels of a pixel back applies the whole output stage to them -- bias, pre-activation copy (O2), GELU, GELU' factor, DropPath row
+// factor, residual (+ mask) -- with its residual / GELU' argument chunk (16 bytes, requested before the staging so that the transpose
+// hides its latency) and stores 16 bytes.  One rounding to bf16 at the end, as on every other path; interior tiles, natural output
+// addressing, Cm % 8 == 0.
+template <int TM, int TN, int FM_, int FN_, int WNW, int NT>
+__device__ __forceinline__ void conv_epilogue_cols(const IGemmArgs& a, f32x4_t (&acc)[FM_][FN_], int tm, int tn, uint16_t* smem, int wm, int wn) {
+    constexpr int ROWB = TM * 4 + 16, ROWS = WNW * 16, CPR = TM / 8, ITERS = ROWS * CPR / NT;       // +16: 16 rows of 16-byte writes cover all banks once
+    static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the column block evenly");
+    const int lane = threadIdx.x & 63;
+    const int mb = wm * (FM_ * 16) + (lane >> 4) * 4;
+    char* stage = reinterpret_cast<char*>(smem);
+    char* my_stage = stage + (wn * 16 + (lane & 15)) * ROWB + mb * 4;                   // + i*64
+    const int ch = threadIdx.x % CPR, lp0 = threadIdx.x / CPR;
+    const uint16_t* in_tile = a.Res ? a.Res : a.dact_pre;         // (the caller excludes Res together with dact_pre, as the half-tile paths do)
+    const float* bias_c = a.bias ? a.bias + tm * TM + ch * 8 : nullptr;
+#pragma unroll
+    for (int j = 0; j < FN_; ++j) {
+        uint32_t gofs[ITERS];                            // byte offset of this thread's chunk (the caller checks the tensor is below 4 GiB)
+        uint4 tin[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int lp = lp0 + it * (NT / CPR);
+            const int pix = tn * TN + (lp >> 4) * (FN_ * 16) + j * 16 + (lp & 15);
+            gofs[it] = ((uint32_t)pix * (uint32_t)a.Cm + (uint32_t)(tm * TM + ch * 8)) * 2u;
+            if (in_tile) tin[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(in_tile) + gofs[it]);
+        }
+#pragma unroll
+        for (int i = 0; i < FM_; ++i) *reinterpret_cast<f32x4_t*>(my_stage + i * 64) = acc[i][j];
+        lds_barrier();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int lp = lp0 + it * (NT / CPR);
+            float v[8];
+            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + lp * ROWB + ch * 32);
+            *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + lp * ROWB + ch * 32 + 16);
+            if (bias_c) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias_c), b1 = *reinterpret_cast<const float4*>(bias_c + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            if (a.O2)
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O2) + gofs[it]) =
+                    make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            if (a.act == 1) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = gelu_f(v[t]);
+            }
+            if (a.dact_pre) {
+                float x8[8];
+                unpack8(tin[it], x8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] *= gelu_grad_f(x8[t]);
+            }
+            if (a.row_scale) {
+                const float rs = a.row_scale[gofs[it] / ((uint32_t)a.Cm * 2u)];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] *= rs;
+            }
+            if (a.Res) {
+                uint4 rv = tin[it];
+                if (a.res_mask) {
+                    const unsigned m = a.res_mask[gofs[it] >> 4];
+                    rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
+                }
+                float r8[8];
+                unpack8(rv, r8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] += r8[t];
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O) + gofs[it]) =
+                make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+        if (j + 1 < FN_) lds_barrier();                  // the read-out is done before the next column block overwrites the stage
+    }
+}
+
 // LIN: 3 = the fused output stage (IGemmArgs::out_scale ... out_mask) in a staged block and in the general path;
 // LIN: 0 = a convolution-only instantiation (no linear-layer extras compiled in at all), 1 = extras in the staged block and in the
 // general path (the LIN kernel variants), 2 = extras in the general path only (kernels without a LIN variant)
 template <int TM, int TN, int FM_, int FN_, int WNW, int NT, int LIN = 2>
 __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&acc)[FM_][FN_], int tm, int tn, uint16_t* smem, int wm, int wn) {
     using Cfg = EpiShape<FM_, FN_>;
-    static_assert(FN_ % 2 == 0, "the staged store splits the tile's pixels in two halves");
+    constexpr bool EVEN = FN_ % 2 == 0;                  // the staged stores below split the tile's pixels in two halves; odd FN: conv_epilogue_cols
     const int lane = threadIdx.x & 63;
     const int mb = wm * (FM_ * 16) + (lane >> 4) * 4, nb = wn * (FN_ * 16) + (lane & 15);
     // Precondition: the caller has synchronised after its main loop (every kernel ends the loop with a barrier that follows
@@ -246,7 +327,10 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     // cost the ResNet step 0.4 ms even when never taken)
     const bool plain_ext = LIN == 1 && !plain && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre);
     const bool interior = (tm + 1) * TM <= a.Cm && (tn + 1) * TN <= a.P;
-    if (plain && interior) {
+    if constexpr (!EVEN) {
+        if (interior && LIN != 3 && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre) && (unsigned long long)a.P * a.Cm * 2ull < 0xffffffffull) { conv_epilogue_cols<TM, TN, FM_, FN_, WNW, NT>(a, acc, tm, tn, smem, wm, wn); return; }
+    }
+    if constexpr (EVEN) if (plain && interior) {
         constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
         constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
         static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
@@ -306,7 +390,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         return;
     }
 
-    if constexpr (LIN == 1) if (plain_ext && interior) {            // linear-layer extras: GELU, pre-activation copy, GELU' factor
+    if constexpr (LIN == 1 && EVEN) if (plain_ext && interior) {            // linear-layer extras: GELU, pre-activation copy, GELU' factor
         constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
         constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
         static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
@@ -399,7 +483,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         return;
     }
 
-    if constexpr (LIN == 3) if (interior && !a.g.sub && (a.Cm & 7) == 0) {     // fused output stage (see IGemmArgs): staged like the lean path
+    if constexpr (LIN == 3 && EVEN) if (interior && !a.g.sub && (a.Cm & 7) == 0) {     // fused output stage (see IGemmArgs): staged like the lean path
         constexpr int ROWB = TM * 2 + 32;
         constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
         static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
@@ -870,10 +954,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a
 template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NW = WM * WN, NT = NW * 64;     // per-wave sub-tile 16 FM x 16 FN
-    constexpr int A_BLK = TM / 8 / NW, B_BLK = TN / 8 / NW, NDMA = A_BLK + B_BLK;
+    constexpr int A_BLK = TM / 8 / NW, B_BLK = (TN / 8 + NW - 1) / NW, NDMA = A_BLK + B_BLK;
+    constexpr bool B_RAGGED = (TN / 8) % NW != 0;        // 320 pixels: 40 pieces over 16 waves, the waves of the upper half skip their third
     constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE_ELEMS = A_ELEMS + B_ELEMS;
     constexpr int AHEAD = NSTAGE - 1;
-    static_assert(NW % 2 == 0 && TM % (8 * NW) == 0 && TN % (8 * NW) == 0, "DMA pieces must divide evenly over an even number of waves");
+    static_assert(NW % 2 == 0 && TM % (8 * NW) == 0 && TN % 8 == 0, "DMA pieces: whole 8-row pieces over an even number of waves");
+    static_assert(!B_RAGGED || NSTAGE == 2, "a ragged piece count needs the wait-for-all of the 2-stage ring (dma_wait<NDMA> counts pieces per wave)");
     static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
@@ -881,6 +967,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    if (a.stamps && tid == 0) {
+        a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw, xcc;                              // where this workgroup sits (slot 10: HW_ID | XCC_ID << 32)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamps[(size_t)blockIdx.x * 12 + 10] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
     const GatherGeom g = a.g;
     const int K = g.R * g.S * g.Ck;                    // weight row length
     const int ktiles = (g.nr * g.ns * g.Ck) >> 6;      // taps actually visited (all of them unless g.sub)
@@ -923,6 +1016,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
         }
 #pragma unroll
         for (int i = 0; i < B_BLK; ++i) {
+            if (B_RAGGED && wave + NW * i >= TN / 8) continue;          // (wave-uniform)
             int hi, wi;
             bool ok = true;
             if (g.mode == 0) { hi = b_h0[i] + kr; wi = b_w0[i] + ks; }
@@ -951,6 +1045,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
     for (; issued < AHEAD && issued < ktiles; ++issued) issue(issued);
     if (issued == 2) dma_wait<NDMA>(); else dma_wait<0>();
     __builtin_amdgcn_s_barrier();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
     int st_cur = 0, st_fill = AHEAD % NSTAGE;
     for (int kt = 0; kt < ktiles; ++kt) {
         if (kt + AHEAD < ktiles) issue(st_fill);
@@ -977,7 +1072,16 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
         st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
     }
     __syncthreads();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
     conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 4 && WN == 4 && NSTAGE == 2 && FM == 4) ? EPI : 2>(a, acc, tm, tn, smem, wm, wn);
+    if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();   // all stores issued (not yet acknowledged)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime();
+            a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued;
+        }
+    }
 }
 
 // Wave-specialised k-tile-64 kernel: WM x WN consumer waves (64 x 64 sub-tiles: fragment reads + MFMAs + epilogue) and NP
@@ -1937,7 +2041,7 @@ namespace dali {
 // Tile configuration per problem (measured on MI355X, scripts/bench_convs.py): 64x256 for <= 64 output channels;
 // 256x256 / 16 waves / 4-deep ring when both K and Cm are large (operand traffic per FLOP halves: +25..36 % on the
 // layer4 3x3); 128x256 / 8 waves for Cm = 128..256 with K >= 1024; 128x128 / 4 waves otherwise (small K: prologue-bound).
-enum ConvCfg { CONV_NARROW = 0, CONV_128 = 1, CONV_128x256 = 2, CONV_256x256 = 3, CONV_256x128 = 4 };
+enum ConvCfg { CONV_NARROW = 0, CONV_128 = 1, CONV_128x256 = 2, CONV_256x256 = 3, CONV_256x128 = 4, CONV_256x320 = 5 };
 static int conv_cfg_override() {
     static int v = -2;
     if (v == -2) { const char* e = getenv("DALI_CONV_CFG"); v = e ? atoi(e) : -1; }
@@ -1950,6 +2054,20 @@ static int conv_k64_mode() {
     if (v == -1) { const char* e = getenv("DALI_CONV_K64"); v = e ? atoi(e) : 2; }
     return v;
 }
+// 256 channels x 320 pixels (k-tile 64, 16 waves of 64 x 80): one workgroup per CU means a launch runs in rounds of 256 tiles, and
+// ViT's 25216 x 768 outputs are 297 tiles of 256 x 256 = 2 rounds for 1.16 rounds of work (measured: 145 us, 144 of 256 CUs busy on
+// average) but 237 tiles of 256 x 320 = one round of 1.25 x the work.  Taken where rounds x tile size says so by a margin; only for
+// launches without BatchNorm statistics (their slab layout is fixed by igemm_conv_stat_tiles before the launch is known).
+// DALI_CONV_320=0 switches it off, DALI_CONV_320_MINK sets the shortest K it is used for (A/B aids).
+static bool conv_prefers_320(int Cm, int P, int K) {
+    static int on = -1, mink = -1;
+    if (on < 0) { const char* e = getenv("DALI_CONV_320"); on = e ? atoi(e) : 1; }
+    if (mink < 0) { const char* e = getenv("DALI_CONV_320_MINK"); mink = e ? atoi(e) : 512; }      // (K = 768: 28.9 -> 28.0..28.6 ms per ViT step against 1024)
+    if (!on || Cm < 512 || P < 16384 || K < mink) return false;
+    const long long tm = (Cm + 255) / 256, t256 = tm * ((P + 255) / 256), t320 = tm * ((P + 319) / 320);
+    const double c256 = (double)((t256 + 255) / 256), c320 = 1.25 * (double)((t320 + 255) / 256);
+    return c320 < 0.85 * c256;
+}
 int conv_pick_cfg(int Cm, int P, int K) {
     if (Cm <= 64) return CONV_NARROW;
     const int ov = conv_cfg_override();
@@ -1959,7 +2077,7 @@ int conv_pick_cfg(int Cm, int P, int K) {
     if (ov == 7) return Cm >= 256 ? CONV_256x128 : CONV_128;
     if (ov == 9) return Cm >= 128 ? CONV_128x256 : CONV_128;
     if (K >= 1024 && P >= 16384) {
-        if (Cm >= 512) return CONV_256x256;
+        if (Cm >= 512) return CONV_256x256;              // (the 128 x 256 tile's finer rounds do not pay for ViT's 297-tile launches: +0.7 ms per step)
         if (Cm >= 128) return CONV_128x256;             // Cm = 128 (layer2 3x3): -18 % against 128 x 128
     }
     if (K >= 512 && P >= 16384 && Cm >= 256) return CONV_128x256;     // ViT linears (K = 768), layer4 conv3 / layer3 downsample
@@ -2050,7 +2168,11 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
     const bool dma_ok = !in_bn && x_bytes < 0x7ff00000ll && (long long)a.Cm * a.g.R * a.g.S * a.g.Ck * 2 < 0x7ff00000ll;
     const int K = a.g.nr * a.g.ns * a.g.Ck;               // reduction length actually visited
-    const int cfg = conv_pick_cfg(a.Cm, a.P, K);
+    int cfg = conv_pick_cfg(a.Cm, a.P, K);
+    const bool fused_out = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;
+    if (!in_bn && dma_ok && !a.stats && !fused_out && !a.g.sub && a.g.Ck % 64 == 0 && (a.Cm & 7) == 0 && conv_k64_mode() == 2 && conv_cfg_override() < 0 &&
+        conv_prefers_320(a.Cm, a.P, K))
+        cfg = CONV_256x320;
     if (!dma_ok && !in_bn && a.stats && (cfg == CONV_128x256 || cfg == CONV_256x256 || cfg == CONV_256x128)) {
         set_error("conv: tensors beyond 2 GiB are not supported together with the BatchNorm statistics epilogue");
         return DALI_ERR_LIMIT;
@@ -2065,7 +2187,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
     static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
     if (k64_min_k < 0) { const char* e = getenv("DALI_CONV_K64_MINK"); k64_min_k = e ? atoi(e) : 1024; }
-    if ((k64 == 2 || k64 == 6) && !(K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
+    if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !(K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
     // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
     // instantiations compile none of it (code that is never executed still cost their register allocation 0.4-0.8 ms per step)
     const bool fused = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;
@@ -2089,15 +2211,22 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
             hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         }
+    } else if (cfg == CONV_256x320) {
+        const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 319) / 320;
+        const int lds = (256 + 320) * 64 * 2 * 2;
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+        hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 5, 1>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_256x256) {
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
-        const int lds = (256 + 256) * 64 * 2 * 2;
+        static int lds_dbg = -1;                           // DALI_DEBUG_K64_LDS: request more LDS than needed (residency experiments)
+        if (lds_dbg < 0) { const char* e = getenv("DALI_DEBUG_K64_LDS"); lds_dbg = e ? atoi(e) : 0; }
+        const int lds = lds_dbg > 0 ? lds_dbg : (256 + 256) * 64 * 2 * 2;
         // (8 waves with 128 x 64 per wave, 25 % fewer LDS fragment bytes, 192 VGPRs: measured 3-5 % slower than 16 waves of 64 x 64)
         // and the wave-specialised form (8 consumers of 128 x 64 + 4 producers, 168 VGPRs, 2-stage ring): -2 % on layer4's 3x3, +14 % on
         // the stride-2 downsample dgrad -- a 256 x 256 tile has no room for producers beside 16 consumers (1024 threads per workgroup)
         DALI_ONCE_PER_DEVICE({
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dbg > 0 ? 163840 : lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dbg > 0 ? 163840 : lds));
         });
         if (lin) hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
@@ -2221,6 +2350,20 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
     const int max_sp = (P + 255) / 256;              // at least 8 k-steps per block
     if (sp > max_sp) sp = max_sp;
     if (sp < 1) sp = 1;
+    // the launch runs in rounds of target_blocks workgroups: rounding the split UP can spill a few workgroups into a second round (ViT's
+    // 768 x 3072 weight: 72 tiles x 8 = 576 for 512 places; 768 x 768: 18 x 15 = 270 for 256), so take the split with the least
+    // rounds(tiles * s) / s instead, the smallest on a tie (fewer slabs).  Power-of-two tile counts (ResNet) keep the split they had.
+    {
+        static int quant = -1;                       // DALI_WGRAD_QUANT=0: the old rule (A/B aid)
+        if (quant < 0) { const char* e = getenv("DALI_WGRAD_QUANT"); quant = e ? atoi(e) : 1; }
+        int best = sp;
+        double best_cost = (double)((tiles * sp + target_blocks - 1) / target_blocks) / sp;
+        for (int c = sp - 1; quant && c >= 1 && c >= sp / 2; --c) {
+            const double cost = (double)((tiles * c + target_blocks - 1) / target_blocks) / c;
+            if (cost <= best_cost + 1e-12) { best = c; best_cost = cost; }
+        }
+        sp = best;
+    }
     int pps = ((P + sp - 1) / sp + 31) & ~31;
     sp = (P + pps - 1) / pps;
     *splits = sp; *pix_per_split = pps;
@@ -2447,6 +2590,15 @@ extern "C" int dali_linear_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, c
     DALI_REQUIRE(K % 32 == 0 && N % 4 == 0 && rows > 0, "dali_linear_fwd: K must be a multiple of 32 and N of 4 (K=%d N=%d)", K, N);
     DALI_REQUIRE(act == 0 || act == 1, "dali_linear_fwd: act must be 0 (none) or 1 (gelu)");
     return launch_linear_fwd((hipStream_t)stream, x, w, bias, act, residual, y, pre, nullptr, rows, K, N);
+}
+/* the same with the whole branch output (bias and activation included) times a per-row factor before the residual is added: DropPath's
+ * per-sample keep / (1 - p) factors expanded to rows (vit_pytorch.py:45-62, applied at :338) */
+extern "C" int dali_linear_fwd_scaled(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, const float* bias, int act,
+                                      const uint16_t* residual, const float* row_scale, uint16_t* y, int rows, int K, int N) {
+    DALI_REQUIRE(ctx && x && w && y && row_scale, "dali_linear_fwd_scaled: null argument");
+    DALI_REQUIRE(K % 32 == 0 && N % 4 == 0 && rows > 0, "dali_linear_fwd_scaled: K must be a multiple of 32 and N of 4 (K=%d N=%d)", K, N);
+    DALI_REQUIRE(act == 0 || act == 1, "dali_linear_fwd_scaled: act must be 0 (none) or 1 (gelu)");
+    return launch_linear_fwd((hipStream_t)stream, x, w, bias, act, residual, y, nullptr, nullptr, rows, K, N, row_scale);
 }
 /* dx[rows,K] = (dy[rows,N] @ wt[K,N]^T) * gelu'(gelu_pre) (+ residual);  wt is the transposed weight image [K][N]. */
 extern "C" int dali_linear_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, const uint16_t* gelu_pre,

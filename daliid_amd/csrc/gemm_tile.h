@@ -168,9 +168,32 @@ __host__ __device__ __forceinline__ void xcd_super_shape(int tiles_m, int tiles_
     ms = tiles_m >= 5 ? 3 : tiles_m >= 3 ? 2 : tiles_m == 2 ? 1 : 0;
     if (ms > lg) ms = lg;
 }
+// When tiles_m is not a multiple of the super-tile's power-of-two height, the super-tile map pads PERIODICALLY (tiles_m = 3: every 4th
+// block of an XCD's sequence is a padding block), and an XCD hands its workgroups to its 4 shader engines round-robin in arrival order:
+// one engine then receives nothing but padding blocks.  Measured with HW_ID stamps on ViT's 25216 x 768 outputs (3 x 99 tiles): only
+// 192 of the 256 CUs ever ran a tile (scripts/conv_block_timeline.py); tiles_m = 9 (768 x 2304) sends the tiles of every second
+// super-tile row to a single engine.  Those shapes take a dense map instead: tiles in the order (band of <= 16 or 8 m-tiles, pixel tile,
+// m) -- m fastest, so a pixel panel is still fetched once per XCD -- cut into 8 contiguous ranges, one per XCD; the only padding blocks
+// are the < 8 at the very end.
+__host__ __device__ __forceinline__ bool xcd_dense_map(int tiles_m, int ms) { return (tiles_m & ((1 << ms) - 1)) != 0; }
 __device__ __forceinline__ bool xcd_tile_map(int b, int tiles_m, int tiles_n, int& tm, int& tn) {
     int lg, ms;
     xcd_super_shape(tiles_m, tiles_n, lg, ms);
+    if (xcd_dense_map(tiles_m, ms)) {
+        const int BM = tiles_m <= 16 ? tiles_m : 8;
+        const int T = tiles_m * tiles_n, per = (T + 7) >> 3;
+        const int xcd = b & 7, slot = b >> 3;
+        const int t = xcd * per + slot;
+        if (slot >= per || t >= T) return false;
+        const int band_tiles = BM * tiles_n;
+        const int band = t / band_tiles;
+        const int r = t - band * band_tiles;
+        const int left = tiles_m - band * BM;
+        const int h = left < BM ? left : BM;
+        tn = r / h;
+        tm = band * BM + (r - tn * h);
+        return true;
+    }
     const int ns = lg - ms;
     const int xcd = b & 7, slot = b >> 3;
     const int ssn = (tiles_n + (1 << ns) - 1) >> ns;
@@ -184,6 +207,7 @@ __device__ __forceinline__ bool xcd_tile_map(int b, int tiles_m, int tiles_n, in
 inline int xcd_tile_grid(int tiles_m, int tiles_n) {
     int lg, ms;
     xcd_super_shape(tiles_m, tiles_n, lg, ms);
+    if (xcd_dense_map(tiles_m, ms)) return ((tiles_m * tiles_n + 7) / 8) * 8;
     const int ns = lg - ms;
     const int ssm = (tiles_m + (1 << ms) - 1) >> ms, ssn = (tiles_n + (1 << ns) - 1) >> ns;
     const int st = ssm * ssn;

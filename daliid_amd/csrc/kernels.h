@@ -106,8 +106,6 @@ int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const f
 // nnops.hip
 constexpr int REDUCE_SMAX = 64;        // rows of the fp64 second-level scratch
 inline size_t reduce_scratch_bytes(int C, int NV) { return (size_t)REDUCE_SMAX * C * NV * sizeof(double); }
-// two-level fp64 sum of `rows` partial rows of `cols` floats: scratch[S][cols] (S <= 16 returned through S_out)
-int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out);
 int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                        float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                        double* scratch);

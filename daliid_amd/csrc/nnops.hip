@@ -3,6 +3,7 @@
 // Encoders.py:333-335: conv1 -> bn1 -> maxpool, NO ReLU), global avg+max pool head (Encoders.py:341-345),
 // BatchNorm1d neck (Encoders.py:350), weight casts/transposes.  All activations NHWC bf16, math fp32.
 #include "kernels.h"
+#include "reduce_finish.h"
 
 namespace dali {
 
@@ -23,53 +24,18 @@ __device__ __forceinline__ void load8f(const float* __restrict__ p, float (&f)[8
 // ------------------------------------------------------------------------------------------------
 // BatchNorm finalise: partial (sum, sumsq) [tiles][C][2] -> mean, invstd, scale = gamma*invstd,
 // shift = beta - mean*scale; running stats updated as torch does (momentum, unbiased variance).
-// One block per 32 channels: 8 tile-slices x 32 channels, fp64 accumulation.
+// fp64 two-level sum and the finish in one launch (reduce_finish.h).
 // ------------------------------------------------------------------------------------------------
-// out[s][col] = sum over rows r = s, s+S, s+2S, ... of in[r][col]  (fp64; fixed order => deterministic).
-// First level of every per-channel reduction: many blocks stream the per-tile partials at HBM speed.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, int rows, int cols, int S, double* __restrict__ out) {
-    const int col = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (col >= cols) return;
-    double acc[8];                                      // 8 independent chains keep 8 loads in flight (latency-bound pass)
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-    int r = s;
-    for (; r + 7 * S < rows; r += 8 * S) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = in[(size_t)(r + u * S) * cols + col];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += (double)v[u];
-    }
-    for (; r < rows; r += S) acc[0] += (double)in[(size_t)r * cols + col];
-    out[(size_t)s * cols + col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int tiles, int C, double count,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                           float momentum, float eps, float* __restrict__ scale,
-                                                           float* __restrict__ shift, float* __restrict__ mean_out,
-                                                           float* __restrict__ invstd_out) {
-    // block = 32 channels x 8 row slices (a single thread walking up to 64 rows was latency-bound: 5-7 us per launch);
-    // slice sums are added in a fixed order
-    __shared__ double red[2][8][32];
-    const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int t = sl; t < tiles; t += 8) {
-            const double2 v = *reinterpret_cast<const double2*>(partial + ((size_t)t * C + c) * 2);
-            a += v.x; b += v.y;
-        }
-    red[0][sl][cx] = a; red[1][sl][cx] = b;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        a = 0.0; b = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
-        const double mean = a / count;
-        double var = b / count - mean * mean;
+// second level of reduce_finish_kernel for the forward statistics (v = {sum, sumsq} of channel c)
+struct FinBnFwd {
+    double count;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    float momentum, eps;
+    float *scale, *shift, *mean_out, *invstd_out;
+    __device__ void operator()(int c, const double* v) const {
+        const double mean = v[0] / count;
+        double var = v[1] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
@@ -83,7 +49,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
     }
-}
+};
 
 // eval mode: scale/shift from the running statistics
 __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -245,32 +211,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
 // partial [blocks][C][NV] -> dgamma = S2, dbeta = S1 and the folded apply coefficients, structure-of-arrays coef [3][C]:
 //   draw = scale*(dz - S1/N - xhat*S2/N),  xhat = (raw - mean)*invstd
 //        = A*dz + K - Q*raw   with  A = scale,  Q = scale*invstd*S2/N,  K = Q*mean - scale*S1/N
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int blocks, int C, int NV,
-                                                               int which, double count, const float* __restrict__ scale,
-                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                               float* __restrict__ coef, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta) {
-    __shared__ double red[2][8][32];                       // 32 channels x 8 row slices per block, fixed-order slice sums
-    const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int t = sl; t < blocks; t += 8) { const double* p = partial + ((size_t)t * C + c) * NV; a += p[0]; b += p[which]; }
-    red[0][sl][cx] = a; red[1][sl][cx] = b;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        a = 0.0; b = 0.0;
+// second level of reduce_finish_kernel for one (NV = 2) or both (NV = 3: v = {S1, S2a, S2b}) BatchNorms behind a gradient
+struct FinBnBwdSide {
+    const float *scale, *mean, *invstd;
+    float *coef, *dgamma, *dbeta;
+};
+template <int NV>
+struct FinBnBwd {
+    double count;
+    int C;
+    FinBnBwdSide side[NV - 1];
+    __device__ void operator()(int c, const double* v) const {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a += red[0][k][cx]; b += red[1][k][cx]; }
-        const double sc = (double)scale[c];
-        const double q = sc * (double)invstd[c] * (b / count);
-        coef[c] = scale[c];
-        coef[C + c] = (float)(q * (double)mean[c] - sc * (a / count));
-        coef[2 * C + c] = (float)q;
-        dgamma[c] = (float)b;
-        dbeta[c] = (float)a;
+        for (int k = 0; k < NV - 1; ++k) {
+            const FinBnBwdSide& s = side[k];
+            const double a = v[0], b = v[1 + k];
+            const double sc = (double)s.scale[c];
+            const double q = sc * (double)s.invstd[c] * (b / count);
+            s.coef[c] = s.scale[c];
+            s.coef[C + c] = (float)(q * (double)s.mean[c] - sc * (a / count));
+            s.coef[2 * C + c] = (float)q;
+            s.dgamma[c] = (float)b;
+            s.dbeta[c] = (float)a;
+        }
     }
-}
+};
 
 template <bool DUAL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ymask,
@@ -846,26 +811,10 @@ static inline int grid_for(size_t work_items, int cap = 16384) {
 }
 
 // ---- host launchers (shared with the net plan) ----------------------------------------------------
-// two-level: `rows` partial rows of `cols` floats -> S fp64 rows in scratch (S <= REDUCE_SMAX)
-int reduce_partials(hipStream_t st, const float* partial, int rows, int cols, double* scratch, int* S_out) {
-    int S = rows / 8;                           // >= 8 rows (one round of 8 loads) per first-level thread
-    if (S < 1) S = 1;
-    if (S > REDUCE_SMAX) S = REDUCE_SMAX;       // the second level (finalize kernels) loops over S rows
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256, S), dim3(256), 0, st, partial, rows, cols, S, scratch);
-    DALI_LAUNCH_CHECK();
-    *S_out = S;
-    return DALI_OK;
-}
-
 int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                        float* rm, float* rv, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                        double* scratch) {
-    int S, rc;
-    if ((rc = reduce_partials(st, partial, tiles, C * 2, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, count, gamma, beta, rm, rv, momentum,
-                       eps, scale, shift, mean, invstd);
-    DALI_LAUNCH_CHECK();
-    return DALI_OK;
+    return launch_reduce_finish<2>(st, partial, tiles, C, scratch, FinBnFwd{count, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd});
 }
 int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                           float* scale, float* shift) {
@@ -908,16 +857,15 @@ int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, cons
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), lds, st, g, ymask, ybits, a, bb, relu, P, C, rpb, partial);
     }
     DALI_LAUNCH_CHECK();
-    int S, rc;
-    if ((rc = reduce_partials(st, partial, blocks, C * NV, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, NV, 1, (double)P, a.scale, a.mean, a.invstd,
-                       coef_a, dgamma_a, dbeta_a);
-    DALI_LAUNCH_CHECK();
+    int rc;
     if (dual) {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, NV, 2, (double)P, bb.scale, bb.mean, bb.invstd,
-                           coef_b, dgamma_b, dbeta_b);
-        DALI_LAUNCH_CHECK();
+        FinBnBwd<3> fin{(double)P, C, {{a.scale, a.mean, a.invstd, coef_a, dgamma_a, dbeta_a}, {bb.scale, bb.mean, bb.invstd, coef_b, dgamma_b, dbeta_b}}};
+        rc = launch_reduce_finish<3>(st, partial, blocks, C, scratch, fin);
+    } else {
+        FinBnBwd<2> fin{(double)P, C, {{a.scale, a.mean, a.invstd, coef_a, dgamma_a, dbeta_a}}};
+        rc = launch_reduce_finish<2>(st, partial, blocks, C, scratch, fin);
     }
+    if (rc) return rc;
     const size_t chunks = (size_t)P * C / 8;
     if (dual) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, ybits, a, bb, coef_a, coef_b, relu, chunks, C, draw_a, draw_b, dz_out);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(chunks)), dim3(256), 0, st, g, ymask, ybits, a, bb, coef_a, coef_a, relu, chunks, C, draw_a, draw_b, dz_out);
@@ -968,11 +916,11 @@ int launch_maxpool_bn_bwd(hipStream_t st, const uint16_t* dp, const uint8_t* arg
     else hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)rif * C * 2 * sizeof(float), st, dp, arg, raw, mean, invstd,
                             N, H, W, C, Ho, Wo, rpb, partial);
     DALI_LAUNCH_CHECK();
-    int S, rc;
-    if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, scratch, S, C, 2, 1, (double)P, scale, mean, invstd, coef,
-                       dgamma, dbeta);
-    DALI_LAUNCH_CHECK();
+    int rc;
+    {
+        FinBnBwd<2> fin{(double)P, C, {{scale, mean, invstd, coef, dgamma, dbeta}}};
+        if ((rc = launch_reduce_finish<2>(st, partial, blocks, C, scratch, fin))) return rc;
+    }
     if ((H & 1) == 0 && (W & 1) == 0)
         hipLaunchKernelGGL(maxpool_bn_bwd_apply_quad_kernel, dim3(grid_for((size_t)N * Ho * Wo * (C / 8))), dim3(256), 0, st, dp, arg, raw, coef, N, H, W, C,
                            Ho, Wo, draw);

@@ -4,6 +4,7 @@
 // Linear layers run on the implicit-GEMM engine of conv.hip (a Linear is a 1x1 convolution over tokens).
 // Activations: tokens [B*T][C] bf16; parameters fp32; statistics / reductions fp32.
 #include "kernels.h"
+#include "reduce_finish.h"
 
 namespace dali {
 
@@ -245,25 +246,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __r
         partial[(size_t)blockIdx.x * C + e] = s;
     }
 }
-// out[c] = sum_s scratch[s][c*stride + which]  (second level of the fp64 two-level sums)
-__global__ void finish_sum_kernel(const double* __restrict__ scratch, int S, int cols, int stride, int which, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    const double* p = scratch + (size_t)c * stride + which;
-    const size_t pitch = (size_t)cols * stride;
-    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // 8 loads in flight (S goes up to 64)
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * pitch];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] += v[u];
-    }
-    for (; s < S; ++s) a[0] += p[(size_t)s * pitch];
-    out[c] = (float)(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
-}
-
 // ------------------------------------------------------------------------------------------------
 // Multi-head self-attention, one block per (batch, head); head_dim 64; T <= 16 * NTILE tokens, NTILE in {13, 14, 16}
 // (197 tokens = ViT-B/16 at 224x224; 211 = TransReID's 256x128 at stride 12, vit_pytorch.py:254-267; up to 256).
@@ -641,13 +623,7 @@ int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, c
     else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<LN_MAXCH>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     DALI_LAUNCH_CHECK();
-    int S, rc;
-    if ((rc = reduce_partials(st, partial, blocks, C * 2, scratch, &S))) return rc;
-    hipLaunchKernelGGL(finish_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 0, dgamma);
-    DALI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(finish_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 2, 1, dbeta);
-    DALI_LAUNCH_CHECK();
-    return DALI_OK;
+    return launch_reduce_finish<2>(st, partial, blocks, C, scratch, FinStore{{dgamma, dbeta, nullptr, nullptr}, 2});
 }
 size_t colsum_partial_floats(int rows, int C) { int rpb; const int rif = 256 / ((C / 8) < 256 ? (C / 8) : 256); return (size_t)rows_blocks(rows, rif, &rpb) * C; }
 // first level only: partial[*n_rows][C] per-block column sums; the caller finishes the sum (bnlin.hip's row kernel)
@@ -666,11 +642,7 @@ int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out
     const int blocks = rows_blocks(rows, rif, &rpb);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), (size_t)rif * C * sizeof(float), st, y, rows, C, rpb, partial);
     DALI_LAUNCH_CHECK();
-    int S, rc;
-    if ((rc = reduce_partials(st, partial, blocks, C, scratch, &S))) return rc;
-    hipLaunchKernelGGL(finish_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, S, C, 1, 0, out);
-    DALI_LAUNCH_CHECK();
-    return DALI_OK;
+    return launch_reduce_finish<1>(st, partial, blocks, C, scratch, FinStore{{out, nullptr, nullptr, nullptr}, 1});
 }
 template <int NTILE, int NW> constexpr size_t att_fwd_lds() {
     return ((size_t)2 * AttGeom<NTILE>::TP * ATT_LD + (size_t)AttGeom<NTILE>::PK * ATT_LD + NW * 16 * ATT_SW) * 2;

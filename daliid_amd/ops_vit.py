@@ -16,6 +16,17 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, want_pre=False):
     return (y, pre) if want_pre else y
 
 
+def linear_fwd_scaled(x, w, row_scale, bias=None, act=0, residual=None):
+    """y = row_scale[:, None] * act(x @ w.T + bias) (+ residual): a residual branch under DropPath (vit_pytorch.py:45-62, :338)."""
+    rows, K = x.shape
+    N = w.shape[0]
+    assert row_scale.shape == (rows,) and row_scale.dtype == torch.float32
+    y = torch.empty(rows, N, device=x.device, dtype=bf16)
+    _lib.check(_lib.lib().dali_linear_fwd_scaled(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16, "x"), _lib.ptr(w, bf16, "w"), _lib.ptr(bias),
+                                                  int(act), _lib.ptr(residual), _lib.ptr(row_scale), _lib.ptr(y), rows, K, N), "dali_linear_fwd_scaled")
+    return y
+
+
 def linear_dgrad(dy, wt, gelu_pre=None, residual=None):
     rows, N = dy.shape
     K = wt.shape[0]

@@ -206,6 +206,10 @@ int dali_bn1d_bwd(dali_ctx* ctx, void* stream, const float* x, const float* dy, 
  * receives the pre-activation.  K % 32 == 0, N % 4 == 0. */
 int dali_linear_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, const float* bias, int act,
                     const uint16_t* residual, uint16_t* y, uint16_t* pre, int rows, int K, int N);
+/* y = row_scale[row] * act(x @ w^T + bias) (+ residual): a residual branch under DropPath (vit_pytorch.py:45-62, applied at :338),
+ * row_scale = the per-sample keep / (1 - p) factors expanded to token rows. */
+int dali_linear_fwd_scaled(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, const float* bias, int act,
+                           const uint16_t* residual, const float* row_scale, uint16_t* y, int rows, int K, int N);
 /* dx = (dy @ wt^T) * gelu'(gelu_pre) (+ residual). */
 int dali_linear_dgrad(dali_ctx* ctx, void* stream, const uint16_t* dy, const uint16_t* wt, const uint16_t* gelu_pre,
                       const uint16_t* residual, uint16_t* dx, int rows, int K, int N);

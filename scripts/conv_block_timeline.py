@@ -9,7 +9,8 @@ MODE = sys.argv[7] if len(sys.argv) > 7 else "fwd"
 x = torch.randn(B, H, W, cin, device="cuda").to(bf16)
 w = torch.randn(cout, k, k, cin, device="cuda").to(bf16)
 dy = torch.randn(B, H, W, cout, device="cuda").to(bf16)
-run = (lambda: nn.conv2d_fwd(x, w, 1, k // 2, want_stats=True)) if MODE == "fwd" else (lambda: nn.conv2d_wgrad(x, dy, (k, k), 1, k // 2))
+STATS = os.environ.get("STATS", "1") != "0"          # STATS=0: a linear layer's launch (no BatchNorm statistics in the epilogue)
+run = (lambda: nn.conv2d_fwd(x, w, 1, k // 2, want_stats=STATS)) if MODE == "fwd" else (lambda: nn.conv2d_wgrad(x, dy, (k, k), 1, k // 2))
 for _ in range(3): run()
 nblk = 1 << 16
 stamps = torch.zeros(nblk, 12, device="cuda", dtype=torch.int64)
@@ -19,11 +20,21 @@ run()
 torch.cuda.synchronize()
 L.dali_debug_set_conv_stamps(None)
 s = stamps.cpu().numpy()
+hw = s[s[:, 3] > 0][:, 10]
 s = s[s[:, 3] > 0].astype(np.float64)
 t0 = s[:, 0].min()
 s = np.where(s > 0, (s - t0) * 10.0 / 1e3, np.nan)           # 100 MHz ticks -> us
 span = np.nanmax(s[:, 3])
 print("blocks stamped: %d ; kernel span %.1f us" % (len(s), span))
+print("blocks started within 3 us of the first: %d ; start-time deciles (us): %s" % (int((s[:, 0] < 3.0).sum()), np.round(np.percentile(s[:, 0], [10, 30, 50, 70, 90, 100]), 1)))
+if (hw != 0).any():                                  # kernels that stamp HW_ID: where did the first round sit?
+    first = s[:, 0] < 3.0
+    xcc, se, cu = (hw >> 32) & 0xf, (hw >> 13) & 0x7, (hw >> 8) & 0xf
+    import collections
+    cnt = collections.Counter(zip(xcc[first].tolist(), se[first].tolist()))
+    print("first-round blocks per (XCC, SE):", dict(sorted(cnt.items())))
+    print("distinct (XCC, SE, CU) in the first round: %d ; over all blocks: %d" % (len(set(zip(xcc[first].tolist(), se[first].tolist(), cu[first].tolist()))),
+                                                                                   len(set(zip(xcc.tolist(), se.tolist(), cu.tolist())))))
 d = s[:, 3] - s[:, 0]
 print("block lifetime us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % (d.mean(), *np.percentile(d, [10, 50, 90]), d.max()))
 names = ["start", "first tile landed", "mainloop done", "end (stores acked)", "all stores issued", "stats done", "half0 staged", "half0 stores issued",

@@ -26,7 +26,10 @@ def close(got, ref, rel=2.0 ** -7, abs_frac=4e-3):
 
 # the last two: >= 16384 rows, i.e. the tiles and kernels the full-size model runs (256 x 256 k-tile 64 with the bias / GELU /
 # residual epilogue, wave-specialised 128 x 256, specialised weight gradient), ragged row count
-@pytest.mark.parametrize("rows,K,N", [(197 * 2, 768, 2304), (100, 3072, 768), (333, 768, 3072), (64, 64, 36), (16500, 3072, 768), (16500, 1024, 384)])
+# (25216, 1024, 768): ViT-B's row count with 768 outputs = the 256 x 320 tile (297 tiles of 256 x 256 would be 2 rounds of 256 CUs) and
+# its column-block epilogue, ragged last tile (25216 = 78 * 320 + 256) through the general path
+@pytest.mark.parametrize("rows,K,N", [(197 * 2, 768, 2304), (100, 3072, 768), (333, 768, 3072), (64, 64, 36), (16500, 3072, 768), (16500, 1024, 384),
+                                      (25216, 1024, 768)])
 def test_linear_fwd_dgrad_wgrad(V, rows, K, N):
     g = torch.Generator().manual_seed(rows + K + N)
     x = torch.randn(rows, K, generator=g).to(bf16)
@@ -42,6 +45,8 @@ def test_linear_fwd_dgrad_wgrad(V, rows, K, N):
     close(prek, pre.detach())
     close(yk, y.detach())
     close(V.linear_fwd(x.cuda(), w.cuda()), F.linear(x.float(), w.float()))
+    rs = (torch.rand(rows, generator=g) < 0.8).float() / 0.8          # DropPath row factors
+    close(V.linear_fwd_scaled(x.cuda(), w.cuda(), rs.cuda(), bias=b.cuda(), residual=res.cuda()), rs[:, None] * pre.detach() + res.float())
     # backward through GELU: dpre = dy * gelu'(pre); dx = dpre @ w
     dpre_ref = torch.autograd.grad(F.gelu(pre.detach().to(bf16).float().requires_grad_(True)).sum(), [])  if False else None
     if N % 32 == 0:
@@ -59,6 +64,20 @@ def test_linear_fwd_dgrad_wgrad(V, rows, K, N):
         ref_dw = dpre.float().t() @ x.float()
         np.testing.assert_allclose(dw.cpu().numpy(), ref_dw.numpy(), rtol=2e-3, atol=2e-3 * float(ref_dw.abs().max()))
         np.testing.assert_allclose(db.cpu().numpy(), dpre.float().sum(0).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_linear_256x320_tile_bit_exact_on_integers(V):
+    """Small integers: every product and fp32 partial sum is exact, so the 256 x 320 kernel (k-tile 64, ragged DMA pieces, transpose-staged
+    store) must equal the fp32 matmul bit for bit, bias and residual included -- interior tiles and the ragged last one."""
+    rows, K, N = 25216, 1024, 768
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (rows, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    b = torch.randint(-8, 9, (N,), generator=g).float()
+    res = torch.randint(-16, 17, (rows, N), generator=g).float()
+    ref = (x.cuda() @ w.cuda().t() + b.cuda() + res.cuda()).to(bf16)          # fp32 matmul of exactly representable values, one rounding
+    got = V.linear_fwd(x.to(bf16).cuda(), w.to(bf16).cuda(), b.cuda(), residual=res.to(bf16).cuda())
+    assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("rows,C", [(197 * 3, 768), (50, 64), (7, 2048)])
