@@ -179,16 +179,21 @@ __device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, unsigned bits) {
 // below the bf16 rounding of the stored result) on v_rcp / v_exp: ocml's erff + expf were ~60 VALU instructions per element, a third of the
 // fc1 / fc2 epilogues' time.  cdf = Phi(v) = 0.5 (1 + erf(v / sqrt 2)), pdf = phi(v); both share exp(-v^2 / 2).
 __device__ __forceinline__ void gelu_parts(float v, float& cdf, float& pdf) {
+    // explicit fused multiply-adds: the library is built with -ffp-contract=off, which left this polynomial as separate multiplies and
+    // adds (~24 VALU issue slots per element; the fc1 / fc2-gradient epilogues spent 7-9 us per half tile in it, 2 us without GELU)
     const float z = fabsf(v) * 0.70710678118654752f;
     const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.44269504088896341f);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * e;
-    cdf = 0.5f * (1.0f + copysignf(erf_abs, v));
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float erf_abs = __builtin_fmaf(-(poly * t), e, 1.0f);
+    cdf = __builtin_fmaf(0.5f, copysignf(erf_abs, v), 0.5f);
     pdf = 0.3989422804014327f * e;
 }
 __device__ __forceinline__ float gelu_f(float v) { float c, p; gelu_parts(v, c, p); return v * c; }
-__device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
+__device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return __builtin_fmaf(x, p, c); }
 __device__ __forceinline__ void unpack8(const uint4& q, float (&f)[8]) {
     f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = bf16_bits_to_f32(q.x >> 16); f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = bf16_bits_to_f32(q.y >> 16);
     f[4] = bf16_bits_to_f32(q.z & 0xffffu); f[5] = bf16_bits_to_f32(q.z >> 16); f[6] = bf16_bits_to_f32(q.w & 0xffffu); f[7] = bf16_bits_to_f32(q.w >> 16);
@@ -825,8 +830,10 @@ __global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void ige
 // budget as the 128 x 128 kernel), block tile (64*WM) x (64*WN).  256 x 256 with 16 waves halves the L2->LDS bytes per
 // FLOP (measured limiter of the 128 x 128 kernel: ~47 GB/s per CU of operand traffic at 0.8 PFLOP/s) and leaves room
 // for a 4-deep LDS ring (3 k-tiles in flight) at one block per CU.
+// (launch bounds: 4 waves per SIMD.  The 8-wave shapes are meant to run two workgroups per CU; their linear-layer instantiation compiled
+// to 130 VGPRs = 3 waves per SIMD = ONE workgroup of 8 waves per CU, and fc1 forward / fc2 data gradient ran at 440 TFLOP/s for it.)
 template <int WM, int WN, int NSTAGE, int EPI = 0>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_conv_wg_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WM * WN * 64, 4) void igemm_conv_wg_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN, NT = NW * 64;
     constexpr int A_BLK = TM / 16 / NW, B_BLK = TN / 16 / NW, NDMA = A_BLK + B_BLK;
     constexpr int A_ELEMS = TM * 32, B_ELEMS = TN * 32, STAGE_ELEMS = A_ELEMS + B_ELEMS;
@@ -2080,7 +2087,10 @@ int conv_pick_cfg(int Cm, int P, int K) {
         if (Cm >= 512) return CONV_256x256;              // (the 128 x 256 tile's finer rounds do not pay for ViT's 297-tile launches: +0.7 ms per step)
         if (Cm >= 128) return CONV_128x256;             // Cm = 128 (layer2 3x3): -18 % against 128 x 128
     }
-    if (K >= 512 && P >= 16384 && Cm >= 256) return CONV_128x256;     // ViT linears (K = 768), layer4 conv3 / layer3 downsample
+    // ViT's K = 768 layers with 2304 / 3072 outputs: 256 x 256 k-tile 64 (qkv forward 120 -> 107 us, fc1 forward 225 -> 203 us against the
+    // 128 x 256 k-tile-32 kernel); ResNet has no K in [768, 1024), and its K = 512 layers lose with either k-tile-64 kernel
+    if (K >= 768 && P >= 16384 && Cm >= 1024) return CONV_256x256;
+    if (K >= 512 && P >= 16384 && Cm >= 256) return CONV_128x256;     // ViT linears (K = 768, 768 outputs: see conv_prefers_320), layer4 conv3 / layer3 downsample
 
     return CONV_128;
 }
@@ -2187,7 +2197,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
     static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
     if (k64_min_k < 0) { const char* e = getenv("DALI_CONV_K64_MINK"); k64_min_k = e ? atoi(e) : 1024; }
-    if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !(K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256))) k64 = 0;
+    if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !((K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256)) || (K >= 768 && cfg == CONV_256x256))) k64 = 0;
     // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
     // instantiations compile none of it (code that is never executed still cost their register allocation 0.4-0.8 ms per step)
     const bool fused = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;

@@ -11,6 +11,13 @@ w = torch.randn(cout, k, k, cin, device="cuda").to(bf16)
 dy = torch.randn(B, H, W, cout, device="cuda").to(bf16)
 STATS = os.environ.get("STATS", "1") != "0"          # STATS=0: a linear layer's launch (no BatchNorm statistics in the epilogue)
 run = (lambda: nn.conv2d_fwd(x, w, 1, k // 2, want_stats=STATS)) if MODE == "fwd" else (lambda: nn.conv2d_wgrad(x, dy, (k, k), 1, k // 2))
+if MODE in ("lin", "lin_gelu", "lin_dgelu"):              # a ViT linear layer of B*H*W rows: plain / fc1 forward (bias + GELU + pre-activation copy) / fc2 data gradient (GELU')
+    from daliid_amd import ops_vit as V
+    xr, wr = x.reshape(-1, cin), w.reshape(cout, cin)
+    bias = torch.randn(cout, device="cuda")
+    pre = torch.randn(B * H * W, cout, device="cuda").to(bf16)
+    run = {"lin": lambda: V.linear_fwd(xr, wr, bias), "lin_gelu": lambda: V.linear_fwd(xr, wr, bias, act=1, want_pre=True),
+           "lin_dgelu": lambda: V.linear_dgrad(xr, wr, gelu_pre=pre)}[MODE]
 for _ in range(3): run()
 nblk = 1 << 16
 stamps = torch.zeros(nblk, 12, device="cuda", dtype=torch.int64)
