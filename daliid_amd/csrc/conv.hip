@@ -325,7 +325,12 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 5] = __builtin_amdgcn_s_memrealtime();     // stats done
 
     // ---- lean path: plain convolution (optionally + residual), interior tile, natural output addressing ----
-    const bool plain = LIN != 3 && !a.O2 && a.act == 0 && !a.dact_pre && !a.row_scale && !a.g.sub && (a.Cm & 7) == 0;   // bias (linear layers) is folded in below
+    // LIN == 4: the lean path with the output addressing of a stride-2 data gradient's parity class (GatherGeom::sub): the pixel rows of
+    // the tile scatter to every second position of every second image row, each still TM * 2 contiguous bytes.  Its own instantiations
+    // (the sub-problems went through the general path before: 8-byte stores per lane, per-element residual loads; layer2's downsample
+    // data gradient 169 us against 71 us forward), so that the hot convolution instantiations stay as they are.
+    constexpr bool SUB = LIN == 4;
+    const bool plain = LIN != 3 && !a.O2 && a.act == 0 && !a.dact_pre && !a.row_scale && (SUB || !a.g.sub) && (a.Cm & 7) == 0;   // bias (linear layers) is folded in below
     // the linear layers' GELU / pre-activation copy (O2) / GELU' factor take a second staged block further down, kept apart so that the
     // convolutions' path stays as lean as it was (folding them into one block cost the ResNet step 0.8 ms)
     // (only in the LIN instantiations of the kernels: compiled into every kernel it changed the convolutions' register allocation and
@@ -350,12 +355,16 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
+            auto row_bytes = [&](int q) -> size_t {             // byte offset of this thread's chunk of tile pixel q (of half h)
+                if constexpr (SUB) return (out_pixel(a.g, tn * TN + h * WROWS + q) * a.Cm + tm * TM + ch * 8) * 2;
+                else return gbase + (size_t)q * a.Cm * 2;
+            };
             if (a.Res) {                                        // residual tile -> LDS with 16-byte loads, same layout as the output
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
                     const int lp = lp0 + it * (NT / CPR);
                     const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
-                    const size_t rb = gbase + (size_t)q * a.Cm * 2;
+                    const size_t rb = row_bytes(q);
                     uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
                     if (a.res_mask) {                           // 16 bytes = 8 channels = one mask byte
                         const unsigned m = a.res_mask[rb >> 4];
@@ -386,7 +395,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
             for (int it = 0; it < ITERS; ++it) {
                 const int lp = lp0 + it * (NT / CPR);
                 const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);                  // pixel inside the tile, minus h*WROWS
-                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O) + gbase + (size_t)q * a.Cm * 2) =
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O) + row_bytes(q)) =
                     *reinterpret_cast<const uint4*>(stage + lp * ROWB + ch * 16);
             }
             if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 12 + 7 + 2 * h] = __builtin_amdgcn_s_memrealtime();   // half's stores issued
@@ -2168,6 +2177,11 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     return launch_igemm_conv_one(st, args);
 }
 
+static bool dgrad_substage() {                          // DALI_DGRAD_SUBSTAGE=0: parity classes through the general epilogue again (A/B aid)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DALI_DGRAD_SUBSTAGE"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const bool in_bn = a.in_scale != nullptr;
     const bool narrow = a.Cm <= 64;
@@ -2220,6 +2234,23 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             using Cfg = GemmCfg<128, 128, 1, 1, 1>;
             const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
             hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
+        }
+    } else if (a.g.sub && !in_bn && dma_ok && !narrow && !lin && (a.Cm & 7) == 0 && conv_cfg_override() < 0 && dgrad_substage()) {
+        // a parity class of a stride-2 data gradient: the staged store with scattered pixel rows (EPI = 4)
+        DALI_ONCE_PER_DEVICE({
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 256) * 64 * 2 * 2));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 256) * 32 * 2 * 3));
+        });
+        if (k64 && cfg == CONV_256x256) {
+            const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
+            hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
+        } else if (cfg == CONV_128x256 || cfg == CONV_256x256) {
+            const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
+            hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), (128 + 256) * 32 * 2 * 3, st, args, tiles_m, tiles_n);
+        } else {
+            using Cfg = GemmCfg<128, 128, 1, 1, 1>;
+            const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
+            hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         }
     } else if (cfg == CONV_256x320) {
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 319) / 320;
