@@ -1721,8 +1721,8 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
 
 // wgrad, wave-grid variant: WM x WN waves of 64 x 64 sub-tiles; the (64*WM) x (64*WN) block tile is held as (TM+TN)/128
 // swizzled [32 px][128 ch] LDS images per stage (same image / tr-read scheme as above), NSTAGE-deep ring.
-template <int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+template <int WM, int WN, int NSTAGE, bool COLSUM = false>
+__global__ __launch_bounds__(WM * WN * 64, 4) void igemm_wgrad_wg_kernel(WGradArgs a, int tiles_m, int tiles_n) {      // (4 waves per SIMD = two 8-wave workgroups per CU: the column-sum variant allocated 136 registers without the bound)
     constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN;
     constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128;
     constexpr int NBLK = NIMG * 8 / NW;                 // 1 KiB DMA blocks per wave per k-step
@@ -1795,6 +1795,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs 
         }
     };
 
+    // COLSUM: column sums of dY over this split's pixels ride on the GEMM as one more MFMA per A fragment against an all-ones operand
+    // (see igemm_wgrad_dma_kernel), in the wn-0 waves, whose A fragments cover each channel of the m tile exactly once.  All n tiles of an
+    // (m tile, split) see the same dY: they share the k-steps round-robin (n tile tn takes kt = tn mod tiles_n) and leave tiles_n partial
+    // rows -- with the n-tile-0 workgroups alone doing it the launch waited for their 25 % longer main loops (6.6 against 5.0 ms per step).
+    // One accumulator for the 4 A fragments: fragment i is multiplied by an operand that is all ones in result columns 4i .. 4i+3 and zero
+    // elsewhere, so column 4i of the 16 x 16 result carries fragment i's row sums (16 accumulator registers for the four sums spilled
+    // inside the main loop of the 128-register kernel).
+    const bool do_cs = COLSUM && wn == 0;
+    int cs_turn = tn;                                    // k-steps until this workgroup's next turn
+    f32x4_t cs = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    typedef unsigned sel_vec_t __attribute__((ext_vector_type(4)));
+    const int cs_col = (lane & 15) >> 2;                 // the fragment whose sums this lane's result column carries
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1828,6 +1840,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
             }
+            if constexpr (COLSUM) if (do_cs) {
+                if (cs_turn == 0) {
+                    int opaque;                          // the select operands are built here, per use: hoisted out of the loop they cost 16 registers
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned w = (cs_col + opaque == i) ? 0x3F803F80u : 0u;        // bf16 (1, 1) or (0, 0)
+                        cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], __builtin_bit_cast(bf16x8_t, sel_vec_t{w, w, w, w}), cs, 0, 0, 0);
+                    }
+                    cs_turn = tiles_n;
+                }
+                --cs_turn;
+            }
             const int left = ksteps - 1 - kt;
             const int inflight_after = left < AHEAD ? left : AHEAD;
             if (inflight_after <= 1) dma_wait<0>();
@@ -1850,12 +1875,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_wgrad_wg_kernel(WGradArgs 
                 if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
             }
         }
+    if constexpr (COLSUM) if (do_cs && (lane & 3) == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int m = m0 + wm * 64 + cs_col * 16 + (lane >> 4) * 4 + rr;
+            if (m < a.Cm) a.colsum[((size_t)ks * tiles_n + tn) * a.Cm + m] = cs[rr];
+        }
+    }
 }
 
 // Wave-specialised variant of igemm_wgrad_wg_kernel: WM x WN consumer waves (transposing fragment reads + MFMAs + the slab
 // store) and NP producer waves (pixel decode, gather arithmetic, DMA pieces), see igemm_conv_k64s_kernel.  One workgroup per
 // CU (16 waves at <= 128 VGPRs), so the ring can be NSTAGE = 4 deep (3 k-steps in flight).
-template <int WM, int WN, int NP, int NSTAGE>
+template <int WM, int WN, int NP, int NSTAGE, bool COLSUM = false>
 __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WGradArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 64 * WM, TN = 64 * WN, NC = WM * WN;
     constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128;
@@ -1953,6 +1985,18 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
     }
     // ---------------- consumers ----------------
     const int wm = wave / WN, wn = wave % WN;
+    // COLSUM: column sums of dY over this split's pixels ride on the GEMM as one more MFMA per A fragment against an all-ones operand
+    // (see igemm_wgrad_dma_kernel), in the wn-0 waves, whose A fragments cover each channel of the m tile exactly once.  All n tiles of an
+    // (m tile, split) see the same dY: they share the k-steps round-robin (n tile tn takes kt = tn mod tiles_n) and leave tiles_n partial
+    // rows -- with the n-tile-0 workgroups alone doing it the launch waited for their 25 % longer main loops (6.6 against 5.0 ms per step).
+    // One accumulator for the 4 A fragments: fragment i is multiplied by an operand that is all ones in result columns 4i .. 4i+3 and zero
+    // elsewhere, so column 4i of the 16 x 16 result carries fragment i's row sums (16 accumulator registers for the four sums spilled
+    // inside the main loop of the 128-register kernel).
+    const bool do_cs = COLSUM && wn == 0;
+    int cs_turn = tn;                                    // k-steps until this workgroup's next turn
+    f32x4_t cs = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    typedef unsigned sel_vec_t __attribute__((ext_vector_type(4)));
+    const int cs_col = (lane & 15) >> 2;                 // the fragment whose sums this lane's result column carries
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1973,6 +2017,19 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
             }
+            if constexpr (COLSUM) if (do_cs) {
+                if (cs_turn == 0) {
+                    int opaque;                          // the select operands are built here, per use: hoisted out of the loop they cost 16 registers
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned w = (cs_col + opaque == i) ? 0x3F803F80u : 0u;        // bf16 (1, 1) or (0, 0)
+                        cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], __builtin_bit_cast(bf16x8_t, sel_vec_t{w, w, w, w}), cs, 0, 0, 0);
+                    }
+                    cs_turn = tiles_n;
+                }
+                --cs_turn;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of this stage are complete before it can be refilled
             __builtin_amdgcn_s_barrier();
             st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
@@ -1990,6 +2047,13 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
                 if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
             }
         }
+    if constexpr (COLSUM) if (do_cs && (lane & 3) == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int m = m0 + wm * 64 + cs_col * 16 + (lane >> 4) * 4 + rr;
+            if (m < a.Cm) a.colsum[((size_t)ks * tiles_n + tn) * a.Cm + m] = cs[rr];
+        }
+    }
 }
 
 // out[e] (= or +=) sum_s partial[s][e]; fixed summation tree => deterministic.  HBM-bound.
@@ -2425,8 +2489,8 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const bool halo_ok = a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && a.g.mode == 0 && args.g.lw >= 0 && args.g.lhw >= 7 &&
                          a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck;
     const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P, halo_ok ? a.g.Wout : 0);
-    if (a.colsum && !(wcfg == 0 && dma_ok && !a.in_scale)) {
-        set_error("wgrad: column sums ride on the 128 x 128 LDS-DMA kernel only (wgrad_colsum_supported)");
+    if (a.colsum && !((wcfg == 0 || wcfg == 2) && dma_ok && !a.in_scale)) {
+        set_error("wgrad: column sums ride on the 128 x 128 and 128 x 256 LDS-DMA kernels only (wgrad_colsum_supported)");
         return DALI_ERR_INVALID;
     }
     if (!a.in_scale && dma_ok && wcfg == 3) {
@@ -2446,9 +2510,17 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
         DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
         });
-        if (wgrad_spec(a.Cm, a.Ntot)) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
-        else hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), dim3(((tm2 * tn2 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm2, tn2);
+        const dim3 grid2(((tm2 * tn2 * a.splits + 7) / 8) * 8);
+        if (wgrad_spec(a.Cm, a.Ntot)) {
+            if (a.colsum) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4, true>), grid2, dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
+            else hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), grid2, dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
+        } else {
+            if (a.colsum) hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3, true>), grid2, dim3(512), lds, st, args, tm2, tn2);
+            else hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), grid2, dim3(512), lds, st, args, tm2, tn2);
+        }
     } else if (a.in_scale) hipLaunchKernelGGL((igemm_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, args, tiles_m, tiles_n);
     else if (dma_ok && a.colsum) hipLaunchKernelGGL(igemm_wgrad_dma_kernel<true>, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
     else if (dma_ok) hipLaunchKernelGGL(igemm_wgrad_dma_kernel<false>, dim3(((tiles_m * tiles_n * a.splits + 7) / 8) * 8), dim3(256), 0, st, args, tiles_m, tiles_n);
@@ -2459,8 +2531,14 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     return launch_splitk_reduce(st, a.partial, out, (size_t)a.Cm * a.Ntot, a.splits, accumulate);
 }
 
+// rows of the column-sum partial slab [rows][Cm] a weight-gradient launch with WGradArgs::colsum leaves: one per split from the
+// 128 x 128 kernel (its n-tile-0 workgroups), one per (split, n tile) from the 128 x 256 kernels (every n tile takes a share)
+int wgrad_colsum_rows(int Cm, int Ntot, int taps, int P, int splits) {
+    return wgrad_pick_cfg(Cm, Ntot, taps, P, 0) == 2 ? splits * ((Ntot + 255) / 256) : splits;
+}
 bool wgrad_colsum_supported(int Cm, int Ntot, int taps, int P) {
-    return wgrad_pick_cfg(Cm, Ntot, taps, P, 0) == 0 && (long long)P * Cm * 2 < 0x7ff00000ll && (long long)P * Ntot * 2 < 0x7ff00000ll;
+    const int cfg = wgrad_pick_cfg(Cm, Ntot, taps, P, 0);
+    return (cfg == 0 || cfg == 2) && (long long)P * Cm * 2 < 0x7ff00000ll && (long long)P * Ntot * 2 < 0x7ff00000ll;
 }
 
 int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate) {
@@ -2609,13 +2687,27 @@ int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, cons
     linear_geom(a.g, K);
     return launch_igemm_conv(st, a);
 }
-int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab) {
+// dbias (nullable) = column sums of dy: they ride on the weight-gradient GEMM (per-split partial sums in cs_partial [splits][N], reduced
+// like the slabs) where the kernel supports it; *bias_done says whether they did (otherwise the caller runs the column-sum pass)
+int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab, float* dbias,
+                        float* cs_partial, bool* bias_done) {
     WGradArgs a{};
     a.dY = dy; a.X = x; a.partial = slab; a.Cm = N; a.P = rows; a.Ntot = K;
     linear_geom(a.g, K);
     size_t wsb;
     wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb);
-    return launch_igemm_wgrad(st, a, dw, 0);
+    static const bool fuse = getenv("DALI_LINEAR_BIAS_FUSED") ? atoi(getenv("DALI_LINEAR_BIAS_FUSED")) != 0 : true;      // (A/B aid)
+    const bool ride = fuse && dbias && cs_partial && wgrad_colsum_supported(N, K, 1, rows);
+    if (bias_done) *bias_done = ride;
+    if (ride) a.colsum = cs_partial;
+    int rc = launch_igemm_wgrad(st, a, dw, 0);
+    if (rc || !ride) return rc;
+    return launch_splitk_reduce(st, cs_partial, dbias, (size_t)N, wgrad_colsum_rows(N, K, 1, rows, a.splits), 0);
+}
+size_t linear_wgrad_colsum_floats(int rows, int K, int N) {
+    int sp, pps; size_t wsb;
+    wgrad_plan(N, K, rows, 512, &sp, &pps, &wsb);
+    return (size_t)wgrad_colsum_rows(N, K, 1, rows, sp) * N;
 }
 size_t linear_wgrad_slab_bytes(int rows, int K, int N) {
     int sp, pps; size_t wsb;
@@ -2654,10 +2746,11 @@ extern "C" int dali_linear_wgrad(dali_ctx* ctx, void* stream, const uint16_t* x,
     DALI_REQUIRE(ctx && x && dy && dw, "dali_linear_wgrad: null argument");
     DALI_REQUIRE(K % 8 == 0 && N % 8 == 0 && rows > 0, "dali_linear_wgrad: K and N must be multiples of 8");
     const size_t slab = align_up(linear_wgrad_slab_bytes(rows, K, N), 256);
-    const size_t part = align_up(colsum_partial_floats(rows, N) * 4, 256);
+    const size_t part = align_up(std::max(colsum_partial_floats(rows, N), linear_wgrad_colsum_floats(rows, K, N)) * 4, 256);
     char* ws = static_cast<char*>(workspace(ctx, slab + part + reduce_scratch_bytes(N, 1)));
     if (!ws) return DALI_ERR_NOMEM;
-    int rc = launch_linear_wgrad((hipStream_t)stream, x, dy, dw, rows, K, N, reinterpret_cast<float*>(ws));
-    if (rc || !dbias) return rc;
+    bool bias_done = false;
+    int rc = launch_linear_wgrad((hipStream_t)stream, x, dy, dw, rows, K, N, reinterpret_cast<float*>(ws), dbias, reinterpret_cast<float*>(ws + slab), &bias_done);
+    if (rc || !dbias || bias_done) return rc;
     return launch_colsum((hipStream_t)stream, dy, rows, N, dbias, reinterpret_cast<float*>(ws + slab), reinterpret_cast<double*>(ws + slab + part));
 }

@@ -87,7 +87,10 @@ int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_
 
 int launch_linear_fwd(hipStream_t st, const uint16_t* x, const uint16_t* w, const float* bias, int act, const uint16_t* residual, uint16_t* y,
                       uint16_t* pre, const uint16_t* dact_pre, int rows, int K, int N, const float* row_scale = nullptr);
-int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab);
+int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* dw, int rows, int K, int N, float* slab,
+                        float* dbias = nullptr, float* cs_partial = nullptr, bool* bias_done = nullptr);
+size_t linear_wgrad_colsum_floats(int rows, int K, int N);
+int wgrad_colsum_rows(int Cm, int Ntot, int taps, int P, int splits);
 size_t linear_wgrad_slab_bytes(int rows, int K, int N);
 
 // bnlin.hip: BatchNorm behind a 1x1 convolution from the moments of the convolution's INPUT (no raw conv output is stored)

@@ -159,8 +159,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
 #pragma unroll
         for (int t = 0; t < 8; ++t) gam[k][t] = (c < C) ? gamma[c + t] : 0.f;
     }
+    // One row per wave and iteration; the NEXT row's g / x / add chunks are requested before this row's arithmetic (a wave walking its 9
+    // rows load -> reduce -> store one after the other exposed one memory round trip per row: 56 us for 116 MB).
+    uint4 ng[NCH], nx[NCH], na[NCH];
+    float nmu = 0.f, nrs = 0.f;
+    auto request = [&](int row) {
+        nmu = mean[row]; nrs = rstd[row];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = (lane + k * 64) * 8;
+            if (c < C) {
+                if (!g32) ng[k] = *reinterpret_cast<const uint4*>(g + (size_t)row * C + c);
+                nx[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * C + c);
+                if (add) na[k] = *reinterpret_cast<const uint4*>(add + (size_t)row * C + c);
+            }
+        }
+    };
+    if (r0 + wave < r1) request(r0 + wave);
     for (int row = r0 + wave; row < r1; row += 4) {
-        const float mu = mean[row], rs = rstd[row];
+        const float mu = nmu, rs = nrs;
+        uint4 cg[NCH], cx[NCH], ca[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { cg[k] = ng[k]; cx[k] = nx[k]; ca[k] = na[k]; }
+        if (row + 4 < r1) request(row + 4);
         float gv[NCH][8], xh[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -172,9 +193,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
 #pragma unroll
                     for (int t = 0; t < 8; ++t) gv[k][t] = g32[(size_t)row * C + c + t];
                 } else {
-                    unpack8v(*reinterpret_cast<const uint4*>(g + (size_t)row * C + c), gv[k]);
+                    unpack8v(cg[k], gv[k]);
                 }
-                unpack8v(*reinterpret_cast<const uint4*>(x + (size_t)row * C + c), xv);
+                unpack8v(cx[k], xv);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     xh[k][t] = (xv[t] - mu) * rs;
@@ -197,7 +218,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                 for (int t = 0; t < 8; ++t) o[t] = rs * (gv[k][t] - s1 - xh[k][t] * s2);
                 if (add) {
                     float a[8];
-                    unpack8v(*reinterpret_cast<const uint4*>(add + (size_t)row * C + c), a);
+                    unpack8v(ca[k], a);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) o[t] += a[t];
                 }

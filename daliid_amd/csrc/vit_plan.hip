@@ -234,8 +234,9 @@ extern "C" int dali_vit_forward(dali_vit* n, void* stream, const float* images, 
 namespace {
 int lin_bwd(dali_vit* n, hipStream_t st, const Lin& l, const uint16_t* x, const uint16_t* dy, const uint16_t* gelu_pre, uint16_t* dx, int rows) {
     int rc;
-    if ((rc = launch_linear_wgrad(st, x, dy, n->G + l.w_off, rows, l.K, l.N, n->slab))) return rc;
-    if ((rc = launch_colsum(st, dy, rows, l.N, n->G + l.b_off, n->partial, n->scratch))) return rc;
+    bool bias_done = false;                                       // the bias gradient rides on the weight-gradient GEMM where the kernel supports it
+    if ((rc = launch_linear_wgrad(st, x, dy, n->G + l.w_off, rows, l.K, l.N, n->slab, n->G + l.b_off, n->partial, &bias_done))) return rc;
+    if (!bias_done && (rc = launch_colsum(st, dy, rows, l.N, n->G + l.b_off, n->partial, n->scratch))) return rc;
     if (dx) return launch_linear_fwd(st, dy, l.wt, nullptr, 0, nullptr, dx, nullptr, gelu_pre, rows, l.N, l.K);
     return DALI_OK;
 }
