@@ -10,7 +10,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdaliid_hip.so")
+LIB_PATH = os.environ.get("DALIID_LIB") or os.path.join(_HERE, "libdaliid_hip.so")      # DALIID_LIB: an A/B build of the same ABI (development aid)
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 

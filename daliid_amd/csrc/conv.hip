@@ -1909,6 +1909,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
     const int p_begin = ks * a.pix_per_split;
     const int p_end = min(a.P, p_begin + a.pix_per_split);
     const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
     if (wave >= NC) {
         // ---------------- producers ----------------
         if (ksteps == 0) return;
@@ -2004,6 +2005,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (ksteps > 0) {
         __builtin_amdgcn_s_barrier();
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
         int st_cur = 0;
         for (int kt = 0; kt < ksteps; ++kt) {
             const uint16_t* sa = smem + st_cur * NIMG * IMG + (wm >> 1) * IMG;
@@ -2035,6 +2037,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
             st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
         }
     }
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
     float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -2053,6 +2056,11 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
             const int m = m0 + wm * 64 + cs_col * 16 + (lane >> 4) * 4 + rr;
             if (m < a.Cm) a.colsum[((size_t)ks * tiles_n + tn) * a.Cm + m] = cs[rr];
         }
+    }
+    if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
     }
 }
 
@@ -2323,15 +2331,13 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 5, 1>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_256x256) {
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
-        static int lds_dbg = -1;                           // DALI_DEBUG_K64_LDS: request more LDS than needed (residency experiments)
-        if (lds_dbg < 0) { const char* e = getenv("DALI_DEBUG_K64_LDS"); lds_dbg = e ? atoi(e) : 0; }
-        const int lds = lds_dbg > 0 ? lds_dbg : (256 + 256) * 64 * 2 * 2;
+        const int lds = (256 + 256) * 64 * 2 * 2;
         // (8 waves with 128 x 64 per wave, 25 % fewer LDS fragment bytes, 192 VGPRs: measured 3-5 % slower than 16 waves of 64 x 64)
         // and the wave-specialised form (8 consumers of 128 x 64 + 4 producers, 168 VGPRs, 2-stage ring): -2 % on layer4's 3x3, +14 % on
         // the stride-2 downsample dgrad -- a 256 x 256 tile has no room for producers beside 16 consumers (1024 threads per workgroup)
         DALI_ONCE_PER_DEVICE({
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dbg > 0 ? 163840 : lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dbg > 0 ? 163840 : lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         });
         if (lin) hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
