@@ -115,6 +115,17 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
+def ranks_seen(world):
+    """number of ranks that took part in a SUM all-reduce of ones on the job's process group (RCCL on a GPU node): the line's
+    world_size_seen is what the collective saw, not what the environment said"""
+    if world == 1:
+        return 1
+    import torch.distributed as dist
+    t = torch.ones(1, device="cuda", dtype=torch.float32)
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
+
+
 def max_over_ranks(x, world):
     if world == 1:
         return x
@@ -191,7 +202,9 @@ def bench_distance(args, world, rank):
         cpu = cpu_baseline_distance()
     return {"metric": "gallery-distance Gpairs/sec", "value": round(gpairs, 3), "unit": "Gpairs/s",
             "ms_per_step": round(ms_step, 4), "dtype": "bf16" if prec == "bf16" else "bf16x3(fp32-grade)",
-            "config": {"workload": "configs[4]: 10k x 100k x 2048 cosine distmat, normalise fused; per GPU",
+            "config": {"workload": "configs[4]: 10k x 100k x 2048 cosine distmat, normalise fused; per GPU; RANDOM features (randn rows, 1000 ids x 100 "
+                                   "gallery / 10 query entries): the ranking kernel's worst case (every gallery entry is binned), so mAP is chance level "
+                                   "by construction and says nothing about accuracy (tests/test_gpu_eval.py covers SURVEY 8d's structured gallery)",
                        "nq": nq, "ng": ng, "d": d, "precision": prec, "mAP_on_random_features": round(float(mAP), 6)},
             "rank_eval_ms": round(rank_ms, 3), "rank_eval_GBps": round(nq * ng * 4 / 1e9 / (rank_ms * 1e-3), 1),
             "rank_eval_hbm_frac": round(nq * ng * 4 / 1e9 / (rank_ms * 1e-3) / HBM_PEAK_GBS, 4),
@@ -440,7 +453,7 @@ def allreduce_probe(tr, world, steps):
     ev1.record()
     barrier_sync(world)
     ms = max_over_ranks(ev0.elapsed_time(ev1) / steps, world)
-    return {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "buckets": len(dp.ranges), "bytes_per_step": n_bytes,
+    return {"backend": dist.get_backend(), "world_size_seen": ranks_seen(world), "buckets": len(dp.ranges), "bytes_per_step": n_bytes,
             "allreduce_ms_per_step": round(ms, 3),
             "bus_GBps": round(2.0 * (world - 1) / world * n_bytes / 1e9 / (ms * 1e-3), 1),
             "note": "standalone (un-overlapped) SUM all-reduce of the flat fp32 gradient buffer in its per-stage buckets; in the timed "
@@ -514,7 +527,7 @@ def main():
     res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
     if world > 1:
-        res["world_size_seen"] = world
+        res["world_size_seen"] = ranks_seen(world)          # from an all-reduce of ones on the NCCL (= RCCL) group
         res["backend"] = backend
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -277,7 +277,8 @@ extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, co
     size_t wsb;
     wgrad_plan(w, w, P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
     const bool fused_cs = wgrad_colsum_supported(w, w, 1, P);
-    const size_t b_cs = align_up(std::max(colsum_partial_floats(P, w), (size_t)wa.splits * w) * 4, 256), b_sc = align_up(reduce_scratch_bytes(w, 1), 256);
+    const int cs_rows = wgrad_colsum_rows(w, w, 1, P, wa.splits);             // one row per split, or per (split, n tile) from the 128 x 256 kernels
+    const size_t b_cs = align_up(std::max(colsum_partial_floats(P, w), (size_t)cs_rows * w) * 4, 256), b_sc = align_up(reduce_scratch_bytes(w, 1), 256);
     const size_t b_wt = align_up((size_t)C * w * 2, 256), b_dot = align_up((size_t)(w / 32) * C * 4, 256);
     char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + b_wt + b_dot));
     if (!ws) return DALI_ERR_NOMEM;
@@ -290,7 +291,7 @@ extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, co
     int rc;
     if (fused_cs) wa.colsum = cs_partial;
     if ((rc = launch_igemm_wgrad(st, wa, gram, 0))) return rc;
-    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, m2, (size_t)w, wa.splits, 0))) return rc; }
+    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, m2, (size_t)w, cs_rows, 0))) return rc; }
     else if ((rc = launch_colsum(st, a, P, w, m2, cs_partial, scratch))) return rc;
     if ((rc = launch_weight_transpose(st, W, C, 1, w, wt))) return rc;
     return launch_bnlin_stats(st, wt, gram, m2, C, w, (double)P, gamma, beta, running_mean, running_var, momentum, eps, ut, dot, scale, shift, mean, invstd);
@@ -307,7 +308,8 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     size_t wsb;
     wgrad_plan(C, w, P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
     const bool fused_cs = wgrad_colsum_supported(C, w, 1, P);
-    const size_t b_cs = align_up(std::max(colsum_partial_floats(P, C), (size_t)wa.splits * C) * 4, 256), b_sc = align_up(reduce_scratch_bytes(C, 1), 256);
+    const int cs_rows = wgrad_colsum_rows(C, w, 1, P, wa.splits);
+    const size_t b_cs = align_up(std::max(colsum_partial_floats(P, C), (size_t)cs_rows * C) * 4, 256), b_sc = align_up(reduce_scratch_bytes(C, 1), 256);
     const size_t b_v = align_up((size_t)C * 4, 256);
     char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + 3 * b_v));
     if (!ws) return DALI_ERR_NOMEM;
@@ -320,7 +322,7 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     int rc;
     if (fused_cs) wa.colsum = cs_partial;
     if ((rc = launch_igemm_wgrad(st, wa, dW, 0))) return rc;                       // G0 -> dW
-    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, sdz, (size_t)C, wa.splits, 0))) return rc; }
+    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, sdz, (size_t)C, cs_rows, 0))) return rc; }
     else if ((rc = launch_colsum(st, dz, P, C, sdz, cs_partial, scratch))) return rc;
     return launch_bnlin_bwd(st, W, ut, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
 }

@@ -34,7 +34,9 @@ def active_ranges(net, params=None):
             if m is None:
                 raise _lib.DaliError("FusedAdam: an optimizer parameter is not a view of this net's flat parameter buffer")
             chosen.add(id(m))
-    segs = sorted((off, off + n, id(p) in chosen and name not in no_grad) for name, p, off, n in table)
+    # requires_grad=False parameters never get a .grad, so torch.optim.Adam skips them even when they are in its list (the reference
+    # builds Adam(model.parameters()), mainKIT.py:99: the ViT's frozen bottleneck.bias is in that list, make_models.py:180-182)
+    segs = sorted((off, off + n, id(p) in chosen and p.requires_grad and name not in no_grad) for name, p, off, n in table)
     total = net.flat_params.numel()
     ranges, cur = [], None
     for i, (b, e, on) in enumerate(segs):

@@ -79,7 +79,61 @@ def test_conv1x1_fused_masked_gradient_stage(nn, P, cin, cout):
     ulp_close(y3, (x.float() @ w.float().T + bias) * keep, 1.5)
 
 
-@pytest.mark.parametrize("P,C,w", [(2048, 128, 32), (8192, 256, 64), (32768, 1024, 256), (4100, 512, 128)])
+def hard_case(P, C, w, seed):
+    """Inputs at the sizes the net plan USES the scheme at (layer1: P = 524288, w = 64; layer2: P = 131072, w = 128 at batch 256) and the
+    w >= 512 shape whose column sums come from (split, n tile) rows, with heavy cancellation in var = E[raw^2] - mean^2: activations with
+    mean 1 / variance 0.25 per feature, and the first 8 output channels with constant-sign weight rows (mean^2 / var = 4 w >= 256 there;
+    a few of the random rows reach 50 as well)."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.relu(0.5 * torch.randn(P, w, generator=g) + 1.0).to(bf16).cuda()
+    W = torch.randn(C, w, generator=g) / w ** 0.5
+    W[:8] = (0.5 + torch.rand(8, 1, generator=g)) / w ** 0.5
+    W = W.to(bf16).cuda()
+    gamma, beta = (0.5 + torch.rand(C, generator=g)).cuda(), (0.2 * torch.randn(C, generator=g)).cuda()
+    return g, a, W, gamma, beta
+
+
+@pytest.mark.parametrize("P,C,w", [(524288, 256, 64), (131072, 512, 128), (32768, 2048, 512)])
+def test_bnlin_forward_statistics_at_plan_sizes(nn, P, C, w):
+    g, a, W, gamma, beta = hard_case(P, C, w, P + C + w)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    raw = a.double() @ W.double().T
+    mean, var = raw.mean(0), raw.var(0, unbiased=False)
+    ratio = (mean * mean / var)
+    assert float(ratio[:8].min()) >= 50 and int((ratio >= 50).sum()) >= 8          # the cancellation the test is about
+    o = nn.bnlin_fwd(a, W, gamma, beta, rm, rv)
+    np.testing.assert_allclose(o["m2"].cpu().numpy(), a.double().sum(0).cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(o["mean"].cpu().numpy(), mean.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    err = ((o["invstd"].double() - invstd) / invstd).abs()
+    print("bnlin invstd at P=%d w=%d: max rel err %.3e (channels with mean^2/var >= 50: %.3e), worst ratio %.0f"
+          % (P, w, float(err.max()), float(err[ratio >= 50].max()), float(ratio.max())))
+    assert float(err.max()) < 1e-3, float(err.max())                               # a quarter of one bf16 ulp of the normalised output
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * var * P / (P - 1)).cpu().numpy(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("P,C,w", [(524288, 256, 64), (131072, 512, 128), (32768, 2048, 512)])
+def test_bnlin_backward_at_plan_sizes(nn, P, C, w):
+    g, a, W, gamma, beta = hard_case(P, C, w, P + C + w + 7)
+    dz = (torch.randn(P, C, generator=g) * (torch.rand(P, C, generator=g) > 0.5)).to(bf16).cuda()
+    ad, Wd, gd, bd = (t.double().clone().requires_grad_(True) for t in (a, W, gamma, beta))
+    out = F.batch_norm(ad @ Wd.T, None, None, gd, bd, True, 0.1, 1e-5)
+    (out * dz.double()).sum().backward()
+    del out
+    fwd = nn.bnlin_fwd(a, W, gamma, beta)
+    o = nn.bnlin_bwd(dz, a, W, fwd)
+    rel = lambda x, r: float((x.double() - r).norm() / r.norm())
+    e_b, e_g, e_w = rel(o["dbeta"], bd.grad), rel(o["dgamma"], gd.grad), rel(o["dW"], Wd.grad)
+    print("bnlin backward at P=%d w=%d: dbeta %.2e dgamma %.2e dW %.2e" % (P, w, e_b, e_g, e_w))
+    assert e_b < 1e-5 and e_g < 1e-3 and e_w < 2e-3, (e_b, e_g, e_w)
+    d_a = nn.conv1x1_fused(dz, o["wd1"], bias=o["bvec"])
+    d_a = nn.conv1x1_fused(a, o["wd2"], residual=d_a, inplace=True)
+    e = rel(d_a, ad.grad)
+    print("bnlin data gradient rel-L2 %.3e" % e)
+    assert e < 1.5e-2, e
+
+
+@pytest.mark.parametrize("P,C,w", [(2048, 128, 32), (8192, 256, 64), (32768, 1024, 256), (4100, 512, 128), (32768, 2048, 512)])
 def test_bnlin_forward_statistics(nn, P, C, w):
     g = torch.Generator().manual_seed(P + C + w)
     a = torch.relu(torch.randn(P, w, generator=g) + 0.3).to(bf16).cuda()            # post-ReLU activations: non-zero channel means
@@ -100,7 +154,7 @@ def test_bnlin_forward_statistics(nn, P, C, w):
     np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * var * P / (P - 1)).cpu().numpy(), rtol=2e-4)
 
 
-@pytest.mark.parametrize("P,C,w", [(2048, 128, 32), (8192, 256, 64), (32768, 1024, 256), (4100, 512, 128)])
+@pytest.mark.parametrize("P,C,w", [(2048, 128, 32), (8192, 256, 64), (32768, 1024, 256), (4100, 512, 128), (32768, 2048, 512)])
 def test_bnlin_backward_matches_autograd(nn, P, C, w):
     """autograd through raw = a W^T -> training-mode batch_norm, in fp64, vs the moment form: dW, dgamma, dbeta and the data gradient
     assembled from the two weight images exactly as the net plan does (two 1x1 data-gradient GEMMs, the second accumulating in place)"""

@@ -222,9 +222,11 @@ def test_overlapping_patches_211_tokens_forward_backward_vs_oracle():
     assert not bad, bad
 
 
-def test_frozen_neck_bias_and_unused_fc_are_not_trained():
+@pytest.mark.parametrize("full_list", [False, True])
+def test_frozen_neck_bias_and_unused_fc_are_not_trained(full_list):
     """make_models.py:181 freezes bottleneck.bias; base.fc is never called (grad None): torch.optim.Adam touches neither, weight
-    decay included.  The fused Adam must leave both bit-identical and move every other parameter like torch.optim.Adam."""
+    decay included.  The fused Adam must leave both bit-identical and move every other parameter like torch.optim.Adam.
+    full_list: the optimizer is built as the reference builds it, Adam(model.parameters()) (mainKIT.py:99), the frozen bias in its list."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from daliid_amd import vit_pytorch as V, optim
@@ -235,7 +237,7 @@ def test_frozen_neck_bias_and_unused_fc_are_not_trained():
     g = torch.Generator().manual_seed(4)
     x = torch.randn(6, 3, 64, 32, generator=g)
     w = torch.randn(6, 128, generator=g)
-    drv = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    drv = torch.optim.Adam(list(net.parameters()) if full_list else [p for p in net.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
     fused = optim.FusedAdam.from_torch(drv, net)
     assert len(fused.ranges) == 2
     before = {k: v.detach().clone() for k, v in net.named_parameters()}

@@ -34,6 +34,9 @@ def test_frozen_and_gradless_parameters_are_skipped():
     assert optim.active_ranges(net) == [(0, 192), (512, 576)]
     # an explicit optimizer list (bench.py passes the requires_grad parameters): same result
     assert optim.active_ranges(net, [p for p in net.parameters() if p.requires_grad]) == [(0, 192), (512, 576)]
+    # the reference's own construction, torch.optim.Adam(model.parameters()) (mainKIT.py:99): the frozen parameter IS in the list, and torch
+    # still skips it because its grad stays None
+    assert optim.active_ranges(net, list(net.parameters())) == [(0, 192), (512, 576)]
     # a list that leaves out w0
     assert optim.active_ranges(net, [net.neck_w]) == [(512, 576)]
 
