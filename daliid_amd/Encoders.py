@@ -131,7 +131,19 @@ class ResNet50ReID(nn.Module):
         self.reset_parameters(seed)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_weights_changed())
         if model_base is not None:
-            self.load_state_dict(model_base.state_dict() if isinstance(model_base, nn.Module) else model_base)
+            self._load_base(model_base.state_dict() if isinstance(model_base, nn.Module) else model_base)
+
+    def _load_base(self, sd):
+        """``ResNet50ReID(model_base)`` as the reference calls it (Encoders.py:33-37, 306-328): model_base is a torchvision ``resnet50``,
+        whose trunk (conv1 ... layer4) is taken over; its classifier ``fc.*`` is dropped (Encoders.py:312-328 never copies it) and
+        ``last_bn`` is this module's own fresh BatchNorm1d (Encoders.py:350).  A state_dict of this class (with ``last_bn.*``) loads whole.
+        Anything else missing or unexpected is an error, as in a strict load."""
+        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+        res = self.load_state_dict(sd, strict=False)
+        missing = [k for k in res.missing_keys if not k.startswith("last_bn.")]
+        if missing or res.unexpected_keys:
+            raise _lib.DaliError("ResNet50ReID(model_base): model_base is not a ResNet-50 trunk (missing %s, unexpected %s)"
+                                 % (missing[:4], list(res.unexpected_keys)[:4]))
 
     # ---- construction helpers -------------------------------------------------------------------
     @staticmethod
@@ -282,6 +294,14 @@ class _DataParallelShim(nn.Module):
 
     def cuda(self, device=None):
         return self
+
+
+def getEnsembles(gpu_indexes):
+    """Encoders.getEnsembles (Encoders.py:245-303) builds ResNet-50 + OSNet + DenseNet-121 pairs; OSNet and DenseNet are outside the
+    scope table.  The name exists so that ``from Encoders import getDCNN, getEnsembles`` (mainKIT.py:27,
+    train_encodersKIT.py:25, evaluateCleanATModels.py:13) keeps importing; mainKIT.main never calls it."""
+    raise NotImplementedError("getEnsembles: the OSNet / DenseNet-121 ensemble members are out of scope of this build (SURVEY.md 2.1); "
+                              "use getDCNN(gpu_indexes, 'resnet50')")
 
 
 def getDCNN(gpu_indexes, model_name, embedding_size=None):

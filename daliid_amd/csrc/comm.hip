@@ -8,6 +8,7 @@
 // touches Python.  xGMI is a point-to-point mesh: buckets that divide by the world size go as reduce-scatter + all-gather on the
 // caller's stream (the two halves of a ring all-reduce, each rank owning count / world elements in between), the rest as ncclAllReduce.
 #include "common.h"
+#include <cstdlib>
 #include <dlfcn.h>
 #include <cstring>
 
@@ -107,7 +108,12 @@ extern "C" int dali_allreduce_bucket(dali_ctx* ctx, void* stream, float* buf, in
     if (!r) return DALI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int world = ctx->comm_world;
-    if (world > 1 && count % world == 0 && ((count / world) * sizeof(float)) % 256 == 0) {
+    // DALIID_COMM_RSAG=1: reduce-scatter + all-gather as two calls (the form SURVEY 8e names for the 7-link xGMI mesh).  Off by default: that
+    // branch has only ever run at world size 1 (no multi-GPU box was available to the builder), and a rank-offset mistake in it would
+    // corrupt every gradient bucket silently; ncclAllReduce is what torch.distributed runs for the same buffers.  Compare the two bit for
+    // bit on a 2-GPU box (tests/test_gpu_dp.py::test_abi_allreduce_matches_torch_distributed covers whichever is selected) before switching.
+    static const bool rsag = getenv("DALIID_COMM_RSAG") && atoi(getenv("DALIID_COMM_RSAG")) != 0;
+    if (rsag && world > 1 && count % world == 0 && ((count / world) * sizeof(float)) % 256 == 0) {
         // in place: rank r keeps the sum of chunk r after the reduce-scatter, then every rank gathers all chunks
         const size_t chunk = (size_t)(count / world);
         float* mine = buf + (size_t)ctx->comm_rank * chunk;

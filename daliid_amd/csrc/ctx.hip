@@ -1,5 +1,6 @@
 // ctx.hip -- context, error string and workspace of libdaliid_hip.
 #include "common.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <new>
@@ -30,6 +31,26 @@ void* workspace(dali_ctx* ctx, size_t bytes) {
     ctx->ws = p;
     ctx->ws_bytes = want;
     return p;
+}
+
+// ---- arrival counters of reduce_finish_kernel (reduce_finish.h): one definition for the whole library ----
+constexpr int RF_SLOTS_ = 128, RF_GROUPS_ = 64;             // = RF_SLOTS, RF_GROUPS of reduce_finish.h (checked there)
+static __device__ unsigned int g_rf_counters[RF_SLOTS_ * RF_GROUPS_];
+
+unsigned rf_next_slot() {
+    static std::atomic<unsigned> n{0};
+    return n.fetch_add(1) % RF_SLOTS_;
+}
+int rf_counter_base(unsigned int** out) {
+    static std::mutex mu;
+    static unsigned int* bases[64] = {};
+    int dev = 0;
+    DALI_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("reduce_finish: device index %d", dev); return DALI_ERR_LIMIT; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!bases[dev]) { DALI_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&bases[dev]), HIP_SYMBOL(g_rf_counters))); }
+    *out = bases[dev];
+    return DALI_OK;
 }
 
 }  // namespace dali

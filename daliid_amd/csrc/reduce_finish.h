@@ -10,14 +10,19 @@
 // counter slots round-robin, so concurrent launches on different streams use different counters unless > RF_SLOTS of them are in flight.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <atomic>
 #include "common.h"
 #include "kernels.h"
 
 namespace dali {
 
-constexpr int RF_SLOTS = 128, RF_GROUPS = 64;
-static __device__ unsigned int g_rf_counters[RF_SLOTS * RF_GROUPS];
+constexpr int RF_SLOTS = 128, RF_GROUPS = 64;            // (ctx.hip sizes the array with the same two numbers)
+// The counter array, the slot dispenser and the per-device address table are defined ONCE, in ctx.hip (this header is included by several
+// translation units; the kernels get the counters as a pointer argument, so they need no access to the symbol).
+// Counters return to zero when the last block of a group leaves.  A launch that faults leaves its slot dirty, but a faulted launch is a
+// sticky HIP error for the whole process, so nothing can run on the slot afterwards; launches on one stream are serialised and may share a
+// slot, and slots only collide when more than RF_SLOTS launches on DIFFERENT streams are in flight at once (the library uses two streams).
+unsigned rf_next_slot();
+int rf_counter_base(unsigned int** out);               // the counter array's address on the current device
 
 template <int NV, class Fin>
 __global__ __launch_bounds__(256) void reduce_finish_kernel(const float* __restrict__ in, int rows, int cols, int S, double* scratch,
@@ -95,20 +100,6 @@ inline int rf_levels(int rows) {
     if (S < 1) S = 1;
     if (S > REDUCE_SMAX) S = REDUCE_SMAX;
     return S;
-}
-
-inline unsigned rf_next_slot() {
-    static std::atomic<unsigned> n{0};
-    return n.fetch_add(1) % RF_SLOTS;
-}
-inline int rf_counter_base(unsigned int** out) {         // the counter array's address on the current device, looked up once
-    static unsigned int* bases[64] = {};
-    int dev = 0;
-    DALI_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) { set_error("reduce_finish: device index %d", dev); return DALI_ERR_LIMIT; }
-    if (!bases[dev]) { DALI_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&bases[dev]), HIP_SYMBOL(g_rf_counters))); }
-    *out = bases[dev];
-    return DALI_OK;
 }
 
 template <int NV, class Fin>

@@ -74,3 +74,9 @@ def extractFeatures(subset, img_height, img_width, model, batch_size, gpu_index=
     if verbose:
         print("Features extracted in %.2f seconds" % (time.time() - start))
     return fvs
+
+
+def get_subset_one_encoder(selected_sample, train_set, topK, encoder, batch_size=500, gpu_index=0):
+    """getFeatures.get_subset_one_encoder (getFeatures.py:306-356): top-K neighbours of one sample, a leftover of the clustering pipeline that
+    mainKIT.py:39 imports and never calls.  Outside the scope table; the name exists so that the import keeps working."""
+    raise NotImplementedError("get_subset_one_encoder is out of scope of this build (SURVEY.md 2.1)")

@@ -73,8 +73,13 @@ def init_abi_comm(device, group=None):
     import ctypes
     from . import _lib
     c = _lib.ctx(device)
-    if getattr(init_abi_comm, "_done", None) == device.index:
+    # one communicator per (device, process group): after destroy_process_group() + init_process_group() in the same process the group
+    # object is a new one and the old communicator (other peers, maybe another world size) must not be reused
+    key = (device.index, id(group if group is not None else dist.group.WORLD), dist.get_world_size(group), dist.get_rank(group))
+    if getattr(init_abi_comm, "_done", None) == key:
         return c
+    if getattr(init_abi_comm, "_done", None) is not None and init_abi_comm._done[0] == device.index:
+        _lib.check(_lib.lib().dali_ctx_comm_destroy(c), "dali_ctx_comm_destroy")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     box = [None]
     if rank == 0:
@@ -84,7 +89,7 @@ def init_abi_comm(device, group=None):
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     idbuf = ctypes.create_string_buffer(box[0], 128)
     _lib.check(_lib.lib().dali_ctx_comm_init(c, idbuf, rank, world), "dali_ctx_comm_init")
-    init_abi_comm._done = device.index
+    init_abi_comm._done = key
     return c
 
 

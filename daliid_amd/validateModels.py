@@ -51,6 +51,15 @@ class validateModels:
         return cmc, mAP
 
 
+class MSMT17_validator:
+    """validateModels.MSMT17_validator (validateModels.py:120-190): MSMT17's train/val balanced-accuracy validation.  mainKIT.main only
+    builds it when ``dataset == 'MSMT17'`` (mainKIT.py:122-124); that dataset branch is outside the scope table.  The
+    name exists so that ``from validateModels import validationManager, MSMT17_validator`` (mainKIT.py:28) keeps importing."""
+
+    def __init__(self, train_images, val_images, trainer, dir_to_save):
+        raise NotImplementedError("MSMT17_validator is out of scope of this build (SURVEY.md 2.1)")
+
+
 class validationManager:
 
     @staticmethod
