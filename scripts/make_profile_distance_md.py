@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_distance/ (from scripts/profile_distance.sh) -> profiles/r01_distance_kernel_stats.{md,csv}."""
 import csv, os, shutil
-RND = os.environ.get("ROUND", "r02")
+RND = os.environ.get("ROUND", "r03")
 src = "gpurun_out/prof_distance"
 shutil.copy(src + "/kernel_stats.csv", "profiles/%s_distance_kernel_stats.csv" % RND)
 last = lambda f: open(src + "/" + f).read().strip().splitlines()[-1]
@@ -26,5 +26,9 @@ try:
                "`scripts/effective_clock.py`: GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time; the 2.5 PFLOP/s dense bf16 peak is quoted at 2.4 GHz):\n\n```\n%s\n```\n" % clk)
 except OSError:
     pass
+if os.path.exists(src + "/pmc_mfma.md"):
+    out.append("\nMFMA utilisation (`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE` in its own run, "
+               "`scripts/pmc_mfma.py`; per launch, 8 launches in the process; bf16x3 issues three MFMA products per algorithmic one):\n")
+    out.append(open(src + "/pmc_mfma.md").read())
 open("profiles/%s_distance_kernel_stats.md" % RND, "w").write("\n".join(out) + "\n")
 print("wrote profiles/%s_distance_kernel_stats.md" % RND)

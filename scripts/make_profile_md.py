@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_<wl>/ (from scripts/profile_train.sh) -> profiles/<ROUND>_<wl>_* (committed summary)."""
 import csv, json, os, shutil, sys
-RND = os.environ.get("ROUND", "r02")
+RND = os.environ.get("ROUND", "r03")
 wl = sys.argv[1] if len(sys.argv) > 1 else "train"
 src, name = "gpurun_out/prof_%s" % wl, {"train": "train_step", "vit": "vit_step"}[wl]
 shutil.copy(src + "/pmc_traffic.json", "profiles/%s_%s_pmc_traffic.json" % (RND, wl))
@@ -41,5 +41,10 @@ out.append("Corrections: %s.\n" % pmc["corrections"])
 out.append("```\n%s\n```\n" % json.dumps(pmc["per_family_bytes_per_step"], indent=1))
 out.append("All kernels: %.1f GB/step; GEMM kernels %.1f GB/step.\n" % (pmc["all_kernels_hbm_bytes_per_step"] / 1e9, pmc["gemm_kernels_hbm_bytes_per_step"] / 1e9))
 out.append(pmd)
+if os.path.exists(src + "/pmc_mfma.md"):
+    out.append("\n## MFMA utilisation (PMC pass 5: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE`, 7 steps in the process)\n")
+    out.append("mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); cu_busy = 4 x SQ_BUSY_CU_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs); "
+               "`scripts/pmc_mfma.py`.\n")
+    out.append(open(src + "/pmc_mfma.md").read())
 open("profiles/%s_%s_kernel_stats.md" % (RND, name), "w").write("\n".join(out))
 print("wrote profiles/%s_%s_kernel_stats.md" % (RND, name))
