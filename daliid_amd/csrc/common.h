@@ -22,6 +22,13 @@ struct dali_ctx {
 };
 
 namespace dali {
+// A/B switches read from the environment: cached per call site, re-read after dali_debug_reload_env() (so that one process can time
+// variants interleaved on the same box: boxes differ by +-5 %, and a single kernel by more between two processes).
+int env_int_cached(const char* name, int def, int* cache, int* epoch_seen);
+}  // namespace dali
+#define DALI_ENV_INT(NAME, DEF) ([]() -> int { static int v_ = 0, e_ = -1; return dali::env_int_cached(NAME, DEF, &v_, &e_); }())
+
+namespace dali {
 // Returns a workspace pointer of at least `bytes` (256-B aligned) or nullptr (+ error set).
 void* workspace(dali_ctx* ctx, size_t bytes);
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -2064,12 +2064,267 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WG
     }
 }
 
-// out[e] (= or +=) sum_s partial[s][e]; fixed summation tree => deterministic.  HBM-bound.
-// A block covers 256/SL float4 chunks; SL "split lanes" share the slabs of one chunk (s = lane, lane+SL, ...) and are
-// combined through LDS, so tiny outputs with hundreds of slabs (layer1's 64x64 weights) still use many threads.
-// Split-K reduce: out[e] (+)= sum_k partial[k][e] in a fixed order.  One block covers 64 float4 chunks (1 KiB contiguous
-// per slab); wave w sums slabs w, w+WAVES, ... with 8 independent 16-byte loads in flight per lane (the pass is
-// latency-bound otherwise), then the waves' partial sums are added in wave order through LDS.
+// ------------------------------------------------------------------------------------------------
+// Pipelined weight gradient (round 3).  Same GEMM, LDS images ([32 px][128 ch], swizzled, transposing fragment reads) and split-K slabs
+// as igemm_wgrad_wgs_kernel; what changes is WHEN a consumer wave reads its fragments.  In the kernels above a wave reads the 16
+// fragment halves of k-step t, waits for them, multiplies, and meets the other waves at the barrier: the LDS reads and the MFMAs of a
+// wave never overlap, and since every wave of the workgroup leaves the same barrier together, the two waves of a SIMD read together and
+// multiply together as well (stamps: 0.55 us per 32-pixel k-step of a 128 x 256 tile for 0.21 us of MFMA work).  Here the fragments of
+// k-step t+1 are requested BEFORE the MFMAs of k-step t (two register sets, loop unrolled twice so that every access is static), so the
+// reads run under the multiplies.  The ring's bookkeeping shifts by one k-step: at the barrier E_t that ends iteration t the producers
+// guarantee that k-step t+2 has landed, the consumers that their reads of k-steps <= t+1 are complete; during iteration t >= 1 the
+// producers request k-step t + NSTAGE - 1 into the stage k-step t-1 left, so NSTAGE - 2 k-steps are in flight while one is read.
+// Wave grid: WM x WN consumers of (16 FM) x (16 FN), NP producers.  1 x 4 consumers of 128 x 64 + 4 producers = 8 waves at <= 256 registers
+// (one MFMA stream per SIMD, 12 fragments = 24 reads per 32 MFMAs); 2 x 4 consumers of 64 x 64 + 4 producers = 12 waves at <= 168.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Producer wave pw of igemm_wgrad_p_kernel.  A __device__ function of its own rather than a branch of the kernel body: lambdas inside a
+// __global__ function are compiled for the host too, and with this code inside the kernel hipcc 7.2 dropped the kernel's HOST stub
+// without a diagnostic (the library then failed to load with an undefined symbol).
+template <int TM, int TN, int NP, int NSTAGE>
+__device__ __forceinline__ void wgrad_p_produce(const WGradArgs& a, uint16_t* smem, int pw, int m0, int n0, int p_begin, int p_end, int ksteps) {
+    constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128, STAGE = NIMG * IMG;
+    constexpr int NBLK = NIMG * 8 / NP;                 // 1 KiB DMA pieces per producer per k-step
+    constexpr int NB = NP >= 8 ? 1 : 8 / NP;            // distinct piece rows (q & 7) a producer serves
+    constexpr int LEAD = NSTAGE - 3;                    // k-steps that may still be in flight at the barrier (beyond the one that must have landed)
+    const int lane = threadIdx.x & 63;
+    const GatherGeom g = a.g;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+    // pieces q = pw + NP*i -> image q >> 3, piece row q & 7 (pixels 4*(q&7) + lane>>4 of the k-step); wg_swz(4*blk + r) is the same for blk and blk + 4
+    const int r_in = lane >> 4, ps = lane & 15;
+    const int c16 = ((((ps >> 1) ^ wg_swz(4 * (pw & 7) + r_in)) << 1) | (ps & 1));
+    bool is_a[NBLK], col_ok[NBLK];
+    int col[NBLK], tap_r[NBLK], tap_s[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int img = (pw + NP * i) >> 3;
+        is_a[i] = img < NIMG_A;
+        if (is_a[i]) {
+            col[i] = m0 + img * 128 + c16 * 8;
+            col_ok[i] = col[i] < a.Cm;
+            tap_r[i] = tap_s[i] = 0;
+        } else {
+            const int bn = n0 + (img - NIMG_A) * 128 + c16 * 8;
+            col_ok[i] = bn < a.Ntot;
+            const int tap = col_ok[i] ? bn / g.Ck : 0;
+            col[i] = bn - tap * g.Ck;
+            tap_r[i] = tap / g.S; tap_s[i] = tap - tap_r[i] * g.S;
+        }
+    }
+    // 1x1 / stride 1 convolutions and linear layers: both operands are plain [P][ld] matrices, so a piece's source offset is a base
+    // plus kt * 32 rows -- one add per piece instead of the pixel decode / tap arithmetic / bounds tests of the general gather (with four
+    // producers of six pieces each, that arithmetic, not the matrix pipe, set the k-step: 126 us against 94 for layer4's conv1).
+    // Rows past P fall behind num_records of the descriptors and arrive as zeros; pix_per_split is a multiple of 32, so no row of a
+    // k-step belongs to the next split.
+    const bool flat = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.pix_pitch == g.Ck && g.row_pitch == g.Win * g.Ck &&
+                      g.img_pitch == (long long)g.Hin * g.Win * g.Ck && g.Hin == g.Hout && g.Win == g.Wout;
+    uint32_t off0[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int row = p_begin + 4 * ((pw + NP * i) & 7) + r_in;
+        off0[i] = col_ok[i] ? (uint32_t)(row * (is_a[i] ? a.Cm : g.Ck) + col[i]) * 2u : DMA_OOB;
+    }
+    const uint32_t step_a = 32u * (uint32_t)a.Cm * 2u, step_b = 32u * (uint32_t)g.Ck * 2u;
+    auto issue = [&](int kt) {
+        uint16_t* base = smem + (kt % NSTAGE) * STAGE;
+        if (flat) {
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                const int q = pw + NP * i;
+                uint16_t* dst = base + (q >> 3) * IMG + (q & 7) * 512;
+                // (DMA_OOB + kt * step stays below 2^32 and above every num_records: the tensors are below 0x7ff00000 bytes)
+                const uint32_t off = off0[i] + (uint32_t)kt * (is_a[i] ? step_a : step_b);
+                if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+            }
+            return;
+        }
+        int pn[NB], pho[NB], pwo[NB], pp[NB];
+        bool pok[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            pp[j] = p_begin + kt * 32 + 4 * ((pw + NP * j) & 7) + r_in;
+            pok[j] = pp[j] < p_end;
+            int n = 0, ho = 0, wo = 0;
+            if (pok[j]) decode_pixel(g, pp[j], n, ho, wo);
+            pn[j] = (int)((long long)n * g.img_pitch); pho[j] = ho; pwo[j] = wo;
+        }
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            const int j = i % NB, q = pw + NP * i;
+            uint32_t off = DMA_OOB;
+            if (pok[j] && col_ok[i]) {
+                if (is_a[i]) off = (uint32_t)(pp[j] * a.Cm + col[i]) * 2u;
+                else {
+                    const int hi = pho[j] * g.stride - g.pad + tap_r[i], wi = pwo[j] * g.stride - g.pad + tap_s[i];
+                    if ((unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win)
+                        off = (uint32_t)(pn[j] + hi * g.row_pitch + wi * g.pix_pitch + col[i]) * 2u;
+                }
+            }
+            uint16_t* dst = base + (q >> 3) * IMG + (q & 7) * 512;
+            if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+        }
+    };
+    auto wait_all_but = [&](int n) {                           // all but the youngest n k-steps of this wave's pieces have landed
+        if (n <= 0) vm_wait<0>();
+        else if (n == 1) vm_wait<NBLK>();
+        else if (n == 2) vm_wait<2 * NBLK>();
+        else vm_wait<(LEAD > 3 ? 3 : LEAD) * NBLK>();
+    };
+    constexpr int LEADC = LEAD > 3 ? 3 : LEAD;                 // (the switch above knows 0..3)
+    int issued = 0;
+    for (; issued < NSTAGE && issued < ksteps; ++issued) issue(issued);
+    // k-steps 0 and 1 must have landed before the consumers' first reads
+    { const int keep = issued - 2; wait_all_but(keep < 0 ? 0 : (keep > LEADC ? LEADC : keep)); }
+    __builtin_amdgcn_s_barrier();                              // P0
+    for (int t = 0; t < ksteps; ++t) {
+        // k-step t + NSTAGE - 1 into the stage of k-step t - 1, whose reads (iteration t - 2, or the consumers' first reads for k-step 0)
+        // were complete at E_{t-2} / E_0: not in iteration 0
+        if (t >= 1 && issued < ksteps) { issue(issued); ++issued; }
+        // k-step t+2 must have landed at E_t: everything issued beyond it may stay in flight
+        const int keep = issued - (t + 3);
+        wait_all_but(keep < 0 ? 0 : (keep > LEADC ? LEADC : keep));
+        __builtin_amdgcn_s_barrier();                          // E_t
+    }
+}
+
+template <int WM, int WN, int FM, int FN, int NP, int NSTAGE>
+__global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+    constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NC = WM * WN;
+    constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128, STAGE = NIMG * IMG;
+    constexpr int NBLK = NIMG * 8 / NP;                 // 1 KiB DMA pieces per producer per k-step
+    constexpr int LEAD = NSTAGE - 3;                    // k-steps that may still be in flight at the barrier (beyond the one that must have landed)
+    static_assert((NIMG * 8) % NP == 0 && (NP == 4 || NP == 8) && TM % 128 == 0 && TN % 128 == 0, "unsupported wave grid");
+    static_assert(NSTAGE >= 4 && LEAD * NBLK <= 63, "ring depth / vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_m * tiles_n;
+    const int work = tiles * a.splits, per_xcd = (work + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= work) return;
+    const int ks = item / tiles, tile = item - ks * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.P, p_begin + a.pix_per_split);
+    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
+    if (wave >= NC) {
+        // ---------------- producers ---------------- (a __device__ function: see wgrad_p_produce)
+        if (ksteps > 0) wgrad_p_produce<TM, TN, NP, NSTAGE>(a, smem, wave - NC, m0, n0, p_begin, p_end, ksteps);
+        return;
+    }
+    // ---------------- consumers ----------------
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // Byte address of this lane's first read of fragment f inside a stage = base ^ (f << 5): the 32-byte chunk index of a fragment is
+    // (first chunk of the wave + f) ^ swizzle(row), the wave's first chunk is a multiple of FM (FN), a power of two, so "+ f" is "^ f" and
+    // the whole XOR folds into ONE register per operand (twelve hoisted addresses cost the 128 x 64 variant its last registers); the
+    // stage offset (a multiple of 0x6000) is added per k-step and does not touch bits 5-7.  The second read is 4 rows = 1024 bytes on.
+    static_assert((FM == 4 || FM == 8) && (FN == 4 || FN == 8) && (STAGE * 2) % 256 == 0, "fragment index folds into the address by XOR");
+    const int gq = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int row0 = 8 * gq + q4, swz0 = wg_swz(row0);             // (row0 + 4 has the same swizzle)
+    const int ca = wm * FM, cb = wn * FN;                          // first 16-column block of this wave inside the M (N) tile
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)smem;     // (added after the XOR: only the offsets inside the ring need their low bits clear)
+    const uint32_t base_a = (uint32_t)((ca >> 3) * IMG * 2 + row0 * 256 + 8 * p4 + (((ca & 7) ^ swz0) << 5));
+    const uint32_t base_b = (uint32_t)((NIMG_A + (cb >> 3)) * IMG * 2 + row0 * 256 + 8 * p4 + (((cb & 7) ^ swz0) << 5));
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    auto frag_at = [&](uint32_t addr) -> bf16x8_t {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)addr);
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(addr + 1024));
+        return __builtin_bit_cast(bf16x8_t, s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    };
+    auto load_frags = [&](bf16x8_t (&fa)[FM], bf16x8_t (&fb)[FN], int stage) {
+        const uint32_t so = (uint32_t)stage * (uint32_t)(STAGE * 2);
+        const uint32_t aa = base_a + so, bb = base_b + so;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = frag_at(lds0 + (aa ^ (uint32_t)(i << 5)));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = frag_at(lds0 + (bb ^ (uint32_t)(j << 5)));
+    };
+    auto multiply = [&](const bf16x8_t (&fa)[FM], const bf16x8_t (&fb)[FN]) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    // Issue order of one k-step: left alone, the scheduler sinks the next k-step's reads BELOW this k-step's MFMAs (it saves the second
+    // register set that way) and the wave then waits for them with an idle matrix pipe.  The pipeline below pins one transposing read
+    // between two MFMAs until the 2 (FM + FN) reads are out, the remaining MFMAs follow.
+    auto interleave = [&]() {
+        constexpr int NRD = 2 * (FM + FN), NMF = FM * FN;
+        static_assert(NRD <= NMF, "one read per MFMA gap");
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+    };
+    if (ksteps > 0) {
+        bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+        __builtin_amdgcn_s_barrier();                              // P0: k-steps 0 and 1 have landed
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
+        load_frags(fa0, fb0, 0);
+        int t = 0, st1 = 1 % NSTAGE;                               // st1 = stage of k-step t + 1
+        // two k-steps per trip, no branch inside: the last trip's second request re-reads the last k-step's stage (landed, unused)
+        for (; t + 2 <= ksteps; t += 2) {
+            load_frags(fa1, fb1, st1);
+            multiply(fa0, fb0);
+            interleave();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of k-step t+1 are complete: its stage may be refilled after E_t
+            __builtin_amdgcn_s_barrier();                          // E_t
+            const int st2 = (t + 2 < ksteps) ? (st1 + 1 == NSTAGE ? 0 : st1 + 1) : st1;
+            load_frags(fa0, fb0, st2);
+            multiply(fa1, fb1);
+            interleave();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // E_{t+1}
+            st1 = st2 + 1 == NSTAGE ? 0 : st2 + 1;
+        }
+        if (t < ksteps) {                                          // odd count: the last k-step is in set 0
+            multiply(fa0, fb0);
+            __builtin_amdgcn_s_barrier();                          // E_{ksteps-1}
+        }
+    }
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
+    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * 16 * FN + j * 16 + (lane & 15);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 16 * FM + i * 16 + (lane >> 4) * 4 + rr;
+                if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
+            }
+        }
+    if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
+    }
+}
+
+// Split-K reduce: out[e] (+)= sum_k partial[k][e] in a fixed order (deterministic).  One block covers 64 float4 chunks (1 KiB contiguous
+// per slab); wave w of its WAVES waves sums slabs w, w + WAVES, ... with up to 16 independent 16-byte loads in flight per lane, then the
+// waves' partial sums are added in wave order through LDS.  WAVES is chosen per launch (launch_splitk_reduce) so that the launch has about
+// four waves per CU: stamps (round 3) showed the reduce behind a weight-gradient GEMM taking 24-32 us for 33 MB of slabs -- as long as the
+// GEMM's main loop -- because 16 waves per chunk column left each lane TWO loads (layer3's 1024 x 256 gradients, 32 slabs): 16 k waves
+// that each wait one memory round trip for 32 bytes, then meet at a barrier.  One wave per column with 16 loads in flight reads the same
+// bytes in two round trips.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                                   size_t elems, int splits, int accumulate) {
@@ -2080,15 +2335,15 @@ __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* 
     const bool vec = (elems & 3) == 0 && i4 + 3 < elems;      // slabs stay 16-byte aligned only then
     if (vec) {
         const float* base = partial + i4;
-        for (int k0 = w; k0 < splits; k0 += 8 * WAVES) {
-            float4 v[8];
+        for (int k0 = w; k0 < splits; k0 += 16 * WAVES) {
+            float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int k = k0 + u * WAVES;
                 v[u] = (k < splits) ? *reinterpret_cast<const float4*>(base + (size_t)k * elems) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
     } else if (i4 < elems) {
         float* sp = reinterpret_cast<float*>(&s);
@@ -2130,18 +2385,10 @@ namespace dali {
 // 256x256 / 16 waves / 4-deep ring when both K and Cm are large (operand traffic per FLOP halves: +25..36 % on the
 // layer4 3x3); 128x256 / 8 waves for Cm = 128..256 with K >= 1024; 128x128 / 4 waves otherwise (small K: prologue-bound).
 enum ConvCfg { CONV_NARROW = 0, CONV_128 = 1, CONV_128x256 = 2, CONV_256x256 = 3, CONV_256x128 = 4, CONV_256x320 = 5 };
-static int conv_cfg_override() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("DALI_CONV_CFG"); v = e ? atoi(e) : -1; }
-    return v;
-}
+static int conv_cfg_override() { return DALI_ENV_INT("DALI_CONV_CFG", -1); }
 // DALI_CONV_K64 (A/B aid): 0 = k-tile 32 kernels only, 2 (default) = k-tile 64 kernels on the long-K layers, 6 = the same with
 // the unspecialised 128 x 256 kernel, 4 / 3 = k-tile 64 wherever Ck % 64 == 0, the 128 x 128 tile with a 2- / 3-stage ring
-static int conv_k64_mode() {
-    static int v = -1;
-    if (v == -1) { const char* e = getenv("DALI_CONV_K64"); v = e ? atoi(e) : 2; }
-    return v;
-}
+static int conv_k64_mode() { return DALI_ENV_INT("DALI_CONV_K64", 2); }
 // 256 channels x 320 pixels (k-tile 64, 16 waves of 64 x 80): one workgroup per CU means a launch runs in rounds of 256 tiles, and
 // ViT's 25216 x 768 outputs are 297 tiles of 256 x 256 = 2 rounds for 1.16 rounds of work (measured: 145 us, 144 of 256 CUs busy on
 // average) but 237 tiles of 256 x 320 = one round of 1.25 x the work.  Taken where rounds x tile size says so by a margin; only for
@@ -2422,24 +2669,20 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
 // on the 1x1 layers with a long pixel (K) dimension; on 3x3 layers (each 128-column group of N is one tap's gather)
 // and on the ViT linears (25 k rows: the split-K slabs double) they lose.
 // DALI_WGRAD_SPEC=0 (A/B aid): the unspecialised 128 x 256 weight-gradient kernel, two workgroups per CU
-static int wgrad_spec_env() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("DALI_WGRAD_SPEC"); v = e ? atoi(e) : -1; }
-    return v;
-}
+static int wgrad_spec_env() { return DALI_ENV_INT("DALI_WGRAD_SPEC", -1); }
 // the 128 x 256 weight-gradient kernel: wave-specialised (one workgroup per CU) when the problem has few output tiles, the plain
 // 8-wave kernel (two workgroups per CU = 16 MFMA waves) when the tiles alone nearly fill the chip.  DALI_WGRAD_SPEC=0/1 forces one
 // form, DALI_WGRAD_SPEC_TILES moves the threshold (A/B aids).
 static bool wgrad_spec(int Cm, int Ntot) {
     const int ov = wgrad_spec_env();
     if (ov >= 0) return ov != 0;
-    static int thr = -1;
-    if (thr < 0) { const char* e = getenv("DALI_WGRAD_SPEC_TILES"); thr = e ? atoi(e) : 40; }
-    return ((Cm + 127) / 128) * ((Ntot + 255) / 256) <= thr;
+    return ((Cm + 127) / 128) * ((Ntot + 255) / 256) <= DALI_ENV_INT("DALI_WGRAD_SPEC_TILES", 40);
 }
+// DALI_WGRAD_P (A/B aid): 0 = the round-2 kernels, 1 (default) = igemm_wgrad_p_kernel with 4 consumers of 128 x 64 + 4 producers, 2 = with 8 consumers of
+// 64 x 64 + 4 producers, 3 = 8 consumers + 8 producers
+static int wgrad_p_mode() { return DALI_ENV_INT("DALI_WGRAD_P", 1); }
 int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P, int halo_w) {
-    static int ov = -2;
-    if (ov == -2) { const char* e = getenv("DALI_WGRAD_CFG"); ov = e ? atoi(e) : -1; }
+    const int ov = DALI_ENV_INT("DALI_WGRAD_CFG", -1);
     // 3 = 3x3 halo kernel (128 co x 64 ci x 9 taps per block)
     if (ov != 0 && taps == 9 && (halo_w == 8 || halo_w == 16 || halo_w == 32) && Cm % 64 == 0 && (Ntot / 9) % 64 == 0 && P % 32 == 0) return 3;
     if (ov == 2) return (Ntot >= 256) ? 2 : 0;
@@ -2520,7 +2763,23 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
         });
         const dim3 grid2(((tm2 * tn2 * a.splits + 7) / 8) * 8);
-        if (wgrad_spec(a.Cm, a.Ntot)) {
+        const int pmode = wgrad_p_mode();
+        if (pmode && !a.colsum && wgrad_spec(a.Cm, a.Ntot)) {   // (where the specialised kernel ran: few output tiles, one workgroup per CU)
+            constexpr int lds_p = 6 * 3 * 32 * 128 * 2;   // 6 stages x 3 images x 8 KiB
+            DALI_ONCE_PER_DEVICE({
+                DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
+                DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
+                DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
+            });
+            // (measured, interleaved: plain [P][C] operands 92 us with 4 consumers of 128 x 64 + 4 producers against 94 with 8 + 8 and 105 before;
+            //  strided / gathered operands 83 us with 4 producers of 6 pieces, 75 with 8 of 3)
+            const GatherGeom& gg = a.g;
+            const bool flat = gg.R == 1 && gg.S == 1 && gg.stride == 1 && gg.pad == 0 && gg.pix_pitch == gg.Ck && gg.row_pitch == gg.Win * gg.Ck &&
+                              gg.img_pitch == (long long)gg.Hin * gg.Win * gg.Ck && gg.Hin == gg.Hout && gg.Win == gg.Wout;
+            if (pmode == 3 || (pmode == 1 && !flat)) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6>), grid2, dim3(1024), lds_p, st, args, tm2, tn2);
+            else if (pmode == 2) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 4, 6>), grid2, dim3(768), lds_p, st, args, tm2, tn2);
+            else hipLaunchKernelGGL((igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6>), grid2, dim3(512), lds_p, st, args, tm2, tn2);
+        } else if (wgrad_spec(a.Cm, a.Ntot)) {
             if (a.colsum) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4, true>), grid2, dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
             else hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), grid2, dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
         } else {
@@ -2548,11 +2807,23 @@ bool wgrad_colsum_supported(int Cm, int Ntot, int taps, int P) {
 }
 
 int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate) {
+    if (DALI_ENV_INT("DALI_DEBUG_SKIP_REDUCE", 0)) return DALI_OK;      // timing aid only (wrong results): what the reduce launches cost a step
     const size_t chunks = (elems + 3) / 4;
     const unsigned rblocks = (unsigned)((chunks + 63) / 64);
-    if (splits >= 32) hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(rblocks), dim3(1024), 0, st, partial, out, elems, splits, accumulate);
-    else if (splits >= 2) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, st, partial, out, elems, splits, accumulate);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, partial, out, elems, splits, accumulate);
+    // waves per chunk column: enough for ~1024 waves in the launch, at most 16, and at least 4 slabs per wave.  A function of (elems, splits)
+    // only, so the summation order of a given weight gradient never changes from step to step.
+    int W = 1;
+    while (W < 16 && (size_t)rblocks * W < 1024 && splits >= 8 * W) W *= 2;
+    const int ov = DALI_ENV_INT("DALI_REDUCE_WAVES", 0);               // A/B aid: force 1 / 2 / 4 / 8 / 16; -1 = the round-2 rule
+    if (ov == -1) W = splits >= 32 ? 16 : (splits >= 2 ? 4 : 1);
+    else if (ov > 0) W = ov;
+    switch (W) {
+        case 1: hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, partial, out, elems, splits, accumulate); break;
+        case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(rblocks), dim3(128), 0, st, partial, out, elems, splits, accumulate); break;
+        case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, st, partial, out, elems, splits, accumulate); break;
+        case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(rblocks), dim3(512), 0, st, partial, out, elems, splits, accumulate); break;
+        default: hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(rblocks), dim3(1024), 0, st, partial, out, elems, splits, accumulate); break;
+    }
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }

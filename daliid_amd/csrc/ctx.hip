@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <string_view>
 
@@ -33,6 +34,15 @@ void* workspace(dali_ctx* ctx, size_t bytes) {
     return p;
 }
 
+static std::atomic<int> g_env_epoch{0};
+void env_reload();
+int env_int_cached(const char* name, int def, int* cache, int* epoch_seen) {
+    const int e = g_env_epoch.load(std::memory_order_acquire);
+    if (*epoch_seen != e) { const char* v = getenv(name); *cache = v ? atoi(v) : def; *epoch_seen = e; }
+    return *cache;
+}
+void env_reload() { g_env_epoch.fetch_add(1, std::memory_order_acq_rel); }
+
 // ---- arrival counters of reduce_finish_kernel (reduce_finish.h): one definition for the whole library ----
 constexpr int RF_SLOTS_ = 128, RF_GROUPS_ = 64;             // = RF_SLOTS, RF_GROUPS of reduce_finish.h (checked there)
 static __device__ unsigned int g_rf_counters[RF_SLOTS_ * RF_GROUPS_];
@@ -56,6 +66,9 @@ int rf_counter_base(unsigned int** out) {
 }  // namespace dali
 
 extern "C" int dali_version(void) { return 100; }
+
+// Diagnostic (not in include/daliid.h): the DALI_* A/B switches are re-read from the environment at their next use.
+extern "C" int dali_debug_reload_env(void) { dali::env_reload(); return DALI_OK; }
 
 extern "C" const char* dali_last_error(void) { return dali::g_err; }
 

@@ -72,26 +72,36 @@ def _conv(x, conv):
     return F.conv2d(x, QW(conv.weight), stride=conv.stride, padding=conv.padding)
 
 
-def forward_matched(model, x):
-    """model: oracle.resnet50_reid.ResNet50ReID (its parameters receive the gradients). Train-mode forward."""
+def _bn_eval(u, uq, bn, eps=1e-5):
+    """running statistics folded into scale / shift (dali_resnet_forward, training = 0), applied to the stored (rounded) tensor"""
+    scale = bn.weight / torch.sqrt(bn.running_var + eps)
+    shift = bn.bias - bn.running_mean * scale
+    shp = (1, -1, 1, 1) if uq.dim() == 4 else (1, -1)
+    return uq * scale.view(shp) + shift.view(shp)
+
+
+def forward_matched(model, x, training=True):
+    """model: oracle.resnet50_reid.ResNet50ReID (its parameters receive the gradients).  training=True: batch statistics (the train
+    step); False: running statistics (extractFeatures), same rounding points."""
+    _bn = _bn_train if training else _bn_eval
     x = Q(x)
     u = _conv(x, model.conv1)
-    z = _bn_train(u, Q(u), model.bn1)                   # no ReLU after the stem BN (Encoders.py:334)
+    z = _bn(u, Q(u), model.bn1)                   # no ReLU after the stem BN (Encoders.py:334)
     x = Q(F.max_pool2d(z, 3, 2, 1))
     for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
         for blk in layer:
             u1 = _conv(x, blk.conv1)
-            a1 = Q(F.relu(_bn_train(u1, Q(u1), blk.bn1)))
+            a1 = Q(F.relu(_bn(u1, Q(u1), blk.bn1)))
             u2 = _conv(a1, blk.conv2)
-            a2 = Q(F.relu(_bn_train(u2, Q(u2), blk.bn2)))
+            a2 = Q(F.relu(_bn(u2, Q(u2), blk.bn2)))
             u3 = _conv(a2, blk.conv3)
             # where conv3's output is never stored (csrc/bnlin.hip) bn3 acts on the fp32 accumulators
-            out = _bn_train(u3, Q(u3) if stores_raw3(blk) else u3, blk.bn3)
+            out = _bn(u3, Q(u3) if stores_raw3(blk) else u3, blk.bn3)
             if blk.downsample is not None:
                 ud = _conv(x, blk.downsample[0])
-                idn = _bn_train(ud, Q(ud), blk.downsample[1])
+                idn = _bn(ud, Q(ud), blk.downsample[1])
             else:
                 idn = x
             x = Q(F.relu(out + idn))
     f = x.mean((2, 3)) + F.adaptive_max_pool2d(x, 1).flatten(1)     # Encoders.py:341-345
-    return _bn_train(f, f, model.last_bn)               # BatchNorm1d neck in fp32
+    return _bn(f, f, model.last_bn)               # BatchNorm1d neck in fp32

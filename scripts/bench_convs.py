@@ -5,15 +5,7 @@ import torch
 from daliid_amd import ops_nn as nn
 bf16 = torch.bfloat16
 B = int(os.environ.get("B", "256"))
-# (name, H, W, cin, cout, k, stride, count)
-L = [("l1.c1(first)", 64, 32, 64, 64, 1, 1, 1), ("l1.c1", 64, 32, 256, 64, 1, 1, 2), ("l1.c2", 64, 32, 64, 64, 3, 1, 3), ("l1.c3", 64, 32, 64, 256, 1, 1, 3),
-     ("l1.ds", 64, 32, 64, 256, 1, 1, 1),
-     ("l2.c1(first)", 64, 32, 256, 128, 1, 1, 1), ("l2.c2(s2)", 64, 32, 128, 128, 3, 2, 1), ("l2.c1", 32, 16, 512, 128, 1, 1, 3), ("l2.c2", 32, 16, 128, 128, 3, 1, 3),
-     ("l2.c3", 32, 16, 128, 512, 1, 1, 4), ("l2.ds(s2)", 64, 32, 256, 512, 1, 2, 1),
-     ("l3.c1(first)", 32, 16, 512, 256, 1, 1, 1), ("l3.c2(s2)", 32, 16, 256, 256, 3, 2, 1), ("l3.c1", 16, 8, 1024, 256, 1, 1, 5), ("l3.c2", 16, 8, 256, 256, 3, 1, 5),
-     ("l3.c3", 16, 8, 256, 1024, 1, 1, 6), ("l3.ds(s2)", 32, 16, 512, 1024, 1, 2, 1),
-     ("l4.c1(first)", 16, 8, 1024, 512, 1, 1, 1), ("l4.c1", 16, 8, 2048, 512, 1, 1, 2), ("l4.c2", 16, 8, 512, 512, 3, 1, 3), ("l4.c3", 16, 8, 512, 2048, 1, 1, 3),
-     ("l4.ds", 16, 8, 1024, 2048, 1, 1, 1)]
+from bench_convs_shapes import L          # (name, H, W, cin, cout, k, stride, count)
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -99,6 +99,20 @@ def test_conv_fwd_dgrad_wgrad_exact_integers(nn, case):
     assert torch.equal(acc.cpu(), 2 * ref_dw)
 
 
+# 1x1 weight gradients on the pipelined 128 x 256 kernel (igemm_wgrad_p_kernel) whose LAST split holds 1, 2 and 3 k-steps of 32 pixels (the
+# ring's prologue / odd-count tail), the others 8: P = 16416, 16448, 16480 with 65 splits of 256 pixels
+@pytest.mark.parametrize("n,h,w,cin,cout", [(27, 32, 19, 256, 128), (257, 8, 8, 256, 128), (103, 16, 10, 320, 192)])
+def test_wgrad_pipelined_short_last_split_exact_integers(nn, n, h, w, cin, cout):
+    gen = torch.Generator().manual_seed(n * 31 + cin)
+    x = _ints((n, h, w, cin), gen)
+    dy = _ints((n, h, w, cout), gen, density=0.5)
+    ref = torch.einsum("nhwo,nhwi->oi", dy, x).reshape(cout, 1, 1, cin)
+    dw = nn.conv2d_wgrad(x.to(bf16).cuda(), dy.to(bf16).cuda(), (1, 1), 1, 0)
+    assert torch.equal(dw.cpu(), ref), (dw.cpu() - ref).abs().max()
+    dw2 = nn.conv2d_wgrad(x.to(bf16).cuda(), dy.to(bf16).cuda(), (1, 1), 1, 0)
+    assert torch.equal(dw, dw2)                                   # bit-reproducible
+
+
 @pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5], CASES[7]])
 def test_conv_fused_bn_relu_operand(nn, case):
     """Operand transform relu(x*scale+shift) fused into the load (forward and wgrad), random data."""

@@ -67,8 +67,10 @@ def nets():
     return ref, net
 
 
-# HIP-vs-twin bounds (train mode, B = 32): provisional until measured on the box
-HIP_TWIN_EMB, HIP_TWIN_COS_MEDIAN, HIP_TWIN_COS_MIN = 5e-2, 0.90, 0.70
+# HIP-vs-twin bounds (train mode, B = 32).  Measured on MI355X (round 3): embedding 3.80e-2, gradient cosine min 0.936 / median 0.956.
+# Train-mode BatchNorm amplifies the summation-order difference between MFMA tiles and torch's CPU GEMM almost as much as it amplifies
+# the bf16 rounding itself (twin-vs-fp32: 5.9e-2), so these cannot be tight; the eval-mode test below is the tight one.
+HIP_TWIN_EMB, HIP_TWIN_COS_MEDIAN, HIP_TWIN_COS_MIN = 5e-2, 0.94, 0.90
 
 
 def test_full_resnet50_train_mode_vs_fp32_oracle(nets):
@@ -112,6 +114,29 @@ def test_full_resnet50_train_mode_vs_fp32_oracle(nets):
     # ... and in absolute terms (the judge's 2e-2 / 0.99 do not hold for ANY bf16-storage implementation of this 53-layer net: the twin
     # measures 5.7e-2 / 0.92 on the CPU alone)
     assert hip_fp32 < 9e-2 and np.median(list(c_fp32.values())) > 0.88 and min(c_fp32.values()) > 0.7
+
+
+def test_full_resnet50_eval_mode_vs_rounding_matched_twin(nets):
+    """Running statistics: no batch-statistic feedback, so HIP and the rounding-matched twin differ by fp32 summation order and by the
+    bf16 roundings that flip on it.  A wiring mistake anywhere in the 53-layer forward (a wrong residual, a skipped ReLU, one BatchNorm
+    with another's coefficients) moves the embedding by >= 1e-2 and fails this bound; the backward wiring is held as tightly per
+    bottleneck by tests/test_gpu_resnet_blocks.py."""
+    ref, net = nets
+    twin = copy.deepcopy(ref).eval()
+    net.load_state_dict(twin.state_dict())
+    net.eval()
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    x = person_images(np.arange(16) % 8, 256, 128, 11)
+    with torch.no_grad():
+        e_twin = forward_matched(twin, x, training=False)
+        e_fp32 = twin(x)
+        e_hip = net(x.cuda()).cpu()
+    hip_twin, twin_fp32 = rel_l2(e_hip, e_twin), rel_l2(e_twin, e_fp32)
+    print("ResNet-50 eval mode: embedding rel-L2 HIP-vs-twin %.3e | twin-vs-fp32 %.3e" % (hip_twin, twin_fp32))
+    assert hip_twin < HIP_TWIN_EVAL_EMB, hip_twin
+
+
+HIP_TWIN_EVAL_EMB = 4e-3          # provisional: to be set from the first measurement
 
 
 @pytest.mark.parametrize("n_ids,noise,map_tol,cmc_slack", [(300, 1.3, 1e-3, 1), (200, 1.9, 1.5e-2, 6)])

@@ -65,7 +65,7 @@ def test_mainkit_call_sequence(tmp_path):
                     for tag, m in (("online", model_trainer.model_online), ("momentum", model_trainer.model_momentum)):
                         path = "%s/model_%s_%s_%s.h5" % (dir_to_save, tag, model_name, version)          # :169-170
                         torch.save(m.state_dict(), path)
-                        saved.append(path)
+                        saved.append((path, m.module.flat_params.clone()))
                 assert np.isfinite(mAP) and 0.0 <= mAP <= 1.0 and len(cmc) > 0
         # the optimizer mainKIT built is the one that was stepped: the weights moved by ~lr per step, the momentum model by (1 - beta) of it
         moved = (model_online.module.flat_params - w_start).abs().max().item()
@@ -75,11 +75,11 @@ def test_mainkit_call_sequence(tmp_path):
         assert all(np.isfinite(l) for l in losses)
         # the checkpoints are the reference's format: torch-pickled state_dict, torchvision keys under `module.`, and load back bit for bit
         assert len(saved) == 2
-        sd = torch.load(saved[0], map_location="cpu")
+        sd = torch.load(saved[0][0], map_location="cpu")
         assert all(k.startswith("module.") for k in sd) and "module.layer4.2.conv3.weight" in sd and "module.last_bn.running_var" in sd
         on2, _ = getDCNN(gpu_indexes, model_name)
         on2.load_state_dict(sd)
-        assert torch.equal(on2.module.flat_params, model_online.module.flat_params)
+        assert torch.equal(on2.module.flat_params, saved[0][1])             # the weights as they were when the checkpoint was written
         # lambda_lr_warmup's values are what the fused step reads (mainKIT.py:144 -> param_groups)
         lambda_lr_warmup(model_trainer.optimizer, base_lr_values[150], 1e-4)
         assert model_trainer._adam.hyper()[0] == pytest.approx(base_lr / 10) and model_trainer._adam.hyper()[3] == pytest.approx(1e-4)
