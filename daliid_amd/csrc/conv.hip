@@ -79,6 +79,23 @@ __device__ __forceinline__ uint4 bn_relu_chunk(uint4 v, const float* __restrict_
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Stride-2 data gradient with all four output-parity classes in one launch (GatherGeom::sub == 2): the grid is four copies of the
+// class's tile grid (class_grid blocks each, a multiple of 8, so a block keeps its XCD), the class with the most taps first so that the
+// short classes fill the launch's tail.  Sets this workgroup's class fields, returns its block index inside the class.
+// Class c: output rows of parity ph = 1 - (c >> 1), columns pw = 1 - (c & 1): for a 3 x 3 / pad 1 kernel 4, 2, 2 and 1 taps.
+__device__ __forceinline__ int parity_block(IGemmArgs& a) {
+    int b = blockIdx.x;
+    if (a.g.sub == 2) {
+        const int cls = b / a.g.class_grid;
+        b -= cls * a.g.class_grid;
+        const int ph = 1 - (cls >> 1), pw = 1 - (cls & 1);
+        a.g.sub = 1; a.g.oph = ph; a.g.opw = pw;
+        a.g.r0 = (ph + a.g.pad) & 1; a.g.rstep = 2; a.g.nr = (a.g.R - a.g.r0 + 1) / 2;
+        a.g.s0 = (pw + a.g.pad) & 1; a.g.sstep = 2; a.g.ns = (a.g.S - a.g.s0 + 1) / 2;
+    }
+    return b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ------------------------------------------------------------------------------------------------
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void ige
     constexpr int A_BLK = TM / 16 / 4, B_BLK = TN / 16 / 4;      // 1 KiB DMA blocks (16 rows x 64 B) per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
-    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    if (!xcd_tile_map(parity_block(a), tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -850,7 +867,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void igemm_conv_wg_kernel(IGemmArg
     static_assert(TM % (16 * NW) == 0 && TN % (16 * NW) == 0, "DMA blocks must divide evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
-    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    if (!xcd_tile_map(parity_block(a), tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -979,7 +996,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
     static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     int tm, tn;
-    if (!xcd_tile_map(blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+    if (!xcd_tile_map(parity_block(a), tiles_m, tiles_n, tm, tn)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -2453,6 +2470,8 @@ struct ProfScope {
 
 // Host-side launchers shared with the net plan (resnet_plan.hip).
 static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a);
+static bool narrow_cm(int Cm) { return Cm <= 64; }
+static bool dgrad_substage() { return DALI_ENV_INT("DALI_DGRAD_SUBSTAGE", 1) != 0; }    // 0: parity classes through the general epilogue again (A/B aid)
 static unsigned long long* g_conv_stamps = nullptr;      // diagnostic only, see dali_debug_set_conv_stamps
 
 // Stride-2 data gradients are split by output parity: output position (2h'+ph, 2w'+pw) only receives the taps
@@ -2478,6 +2497,16 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
             ns[ph] = s0 < g.S ? (g.S - s0 + 1) / 2 : 0;
         }
         const bool all_have = nr[0] && nr[1] && ns[0] && ns[1];
+        // every class has taps (3x3): ONE launch, the workgroups of the four classes interleaved (parity_block); the four separate launches
+        // of a quarter of the pixels each ran one after the other with a short-K tail each.  DALI_DGRAD_MERGE=0: separate launches (A/B aid)
+        if (all_have && !narrow_cm(a.Cm) && (a.Cm & 7) == 0 && DALI_ENV_INT("DALI_DGRAD_MERGE", 1) && DALI_ENV_INT("DALI_CONV_CFG", -1) < 0 && dgrad_substage()) {
+            IGemmArgs s = args;
+            s.g.sub = 2; s.g.oph = s.g.opw = 0; s.g.Hfull = g.Hout; s.g.Wfull = g.Wout;
+            s.g.Hout = g.Hout / 2; s.g.Wout = g.Wout / 2; s.P = a.P / 4;
+            s.g.r0 = s.g.s0 = 0; s.g.rstep = s.g.sstep = 2;
+            s.g.nr = nr[0] > nr[1] ? nr[0] : nr[1]; s.g.ns = ns[0] > ns[1] ? ns[0] : ns[1];      // the longest class picks the kernel
+            return launch_igemm_conv_one(st, s);
+        }
         if (all_have || (a.Res != nullptr && a.Res == a.O)) {
             for (int ph = 0; ph < 2; ++ph)
                 for (int pw = 0; pw < 2; ++pw) {
@@ -2496,11 +2525,6 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     return launch_igemm_conv_one(st, args);
 }
 
-static bool dgrad_substage() {                          // DALI_DGRAD_SUBSTAGE=0: parity classes through the general epilogue again (A/B aid)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DALI_DGRAD_SUBSTAGE"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
 static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const bool in_bn = a.in_scale != nullptr;
     const bool narrow = a.Cm <= 64;
@@ -2521,7 +2545,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         return DALI_ERR_LIMIT;
     }
     {
-    ProfScope prof_scope(st, 0, 2.0 * a.Cm * (double)a.P * K);
+    ProfScope prof_scope(st, 0, a.g.sub == 2 ? 2.0 * a.Cm * (double)a.P * a.g.R * a.g.S * a.g.Ck : 2.0 * a.Cm * (double)a.P * K);
     // k-tile 64 pays where the main loop dominates (K >= 1024); with a short K or the 128 x 128 tile the smaller k-tile's 2-3
     // co-resident workgroups overlap their epilogues better (measured per layer: 256 x 256 -12..-15 %; 128 x 256 wave-specialised
     // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
@@ -2560,16 +2584,20 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 256) * 64 * 2 * 2));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 256) * 32 * 2 * 3));
         });
+        const int ncls = a.g.sub == 2 ? 4 : 1;          // sub == 2: the four classes in one launch, class_grid workgroups each (parity_block)
         if (k64 && cfg == CONV_256x256) {
             const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
-            hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
+            args.g.class_grid = xcd_tile_grid(tiles_m, tiles_n);
+            hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 4>), dim3(ncls * args.g.class_grid), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
         } else if (cfg == CONV_128x256 || cfg == CONV_256x256) {
             const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
-            hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), (128 + 256) * 32 * 2 * 3, st, args, tiles_m, tiles_n);
+            args.g.class_grid = xcd_tile_grid(tiles_m, tiles_n);
+            hipLaunchKernelGGL((igemm_conv_wg_kernel<2, 4, 3, 4>), dim3(ncls * args.g.class_grid), dim3(512), (128 + 256) * 32 * 2 * 3, st, args, tiles_m, tiles_n);
         } else {
             using Cfg = GemmCfg<128, 128, 1, 1, 1>;
             const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
-            hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 4>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
+            args.g.class_grid = xcd_tile_grid(tiles_m, tiles_n);
+            hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 4>), dim3(ncls * args.g.class_grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         }
     } else if (cfg == CONV_256x320) {
         const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 319) / 320;

@@ -16,8 +16,11 @@ struct GatherGeom {
     // stride-2 dgrad by output parity (set by launch_igemm_conv; LDS-DMA kernels only): the GEMM enumerates the sub-grid
     // (n, ho', wo') of output positions (2ho'+oph, 2wo'+opw) of a Hfull x Wfull tensor; only the taps whose parity
     // matches contribute: kr = r0, r0+2, ... (nr of them), ks = s0, s0+2, ... (ns).  sub == 0: r0 = s0 = 0, all taps.
+    // sub == 2: all four parity classes in ONE launch of 4 * class_grid workgroups; a workgroup derives its class from its block index
+    // (parity_block, conv.hip: the 4-tap class first) and then runs as sub == 1
     int sub, oph, opw, Hfull, Wfull;
     int r0, rstep, nr, s0, sstep, ns;
+    int class_grid;
 };
 
 struct IGemmArgs {

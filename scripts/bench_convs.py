@@ -32,7 +32,13 @@ for name, H, W, cin, cout, k, st, cnt in L:
     byt = (x.numel() + dy.numel()) * 2
     roof = max(fl / 2.5e15, byt / 6e12) * 1e6
     tf = timeit(lambda: nn.conv2d_fwd(x, w, st, pad, want_stats=True))
-    td = timeit(lambda: nn.conv2d_dgrad(dy, wt, (H, W), st, pad))
+    if k == 1 and st == 2:
+        # the plan accumulates a stride-2 1x1 (downsample) data gradient in place onto conv1's (resnet_plan.hip: block_backward): only the
+        # even-even quarter of the positions is touched.  Without a residual the same call has to write zeros to the other three quarters.
+        dxbuf = torch.randn(B, H, W, cin, device="cuda").to(bf16)
+        td = timeit(lambda: nn.conv2d_dgrad(dy, wt, (H, W), st, pad, residual=dxbuf, inplace=True))
+    else:
+        td = timeit(lambda: nn.conv2d_dgrad(dy, wt, (H, W), st, pad))
     tw = timeit(lambda: nn.conv2d_wgrad(x, dy, (k, k), st, pad))
     print("%-14s %8.1f | %9.1f %9.1f %9.1f | %8.1f x%d   eff fwd %.0f%% dg %.0f%% wg %.0f%%" % (name, fl / 1e9, tf, td, tw, roof, cnt, 100 * roof / tf, 100 * roof / td, 100 * roof / tw))
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt; tot["roof"] += roof * cnt
