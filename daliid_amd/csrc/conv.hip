@@ -1736,6 +1736,172 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
     }
 }
 
+// The same kernel, software-pipelined (round 3; NOT the default: it measured 5 % slower, see launch_igemm_wgrad).  Above, every wave requests its 3 DMA pieces, reads its 26 fragment halves, waits,
+// multiplies and meets the others at the barrier: per k-step 450 cycles of DMA issue + 550 of reads + 800 of MFMAs in sequence (diagnostic
+// stamps), both waves of a SIMD in the same part at the same time, the matrix pipe busy a third of the time (PMC mfma_busy 0.35).
+// Tried first and refuted: the two wave groups half a k-step apart ("ping-pong", one group reads while its SIMD partners multiply):
+// the read part (1300 cycles) is 1.6 x the multiply part, the multiplying group waits for the reading one, 195 us against 154.
+// Here a wave requests the NEXT k-step's fragments between the MFMAs of this one: tap k's two B reads right behind tap k's four MFMAs,
+// into the registers those MFMAs have just read (B needs no second register set), the three DMA pieces behind taps 2, 5 and 8, the eight
+// A reads behind the last tap.  The ring's bookkeeping is that of igemm_wgrad_p_kernel: at the barrier E_t that ends
+// iteration t every wave has waited for its own pieces of k-step t+2 and for its reads of k-step t+1; in iteration t >= 1 it requests
+// k-step t + NSTAGE - 1 into the stage k-step t - 1 left.
+template <int NSTAGE>
+__global__ __launch_bounds__(512) void igemm_wgrad3x3_p_kernel(WGradArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles = tiles_m * tiles_n;
+    const int work = tiles * a.splits, per_xcd = (work + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= work) return;
+    const int ks = item / tiles, tile = item - ks * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 128, ci0 = tn * 64;
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
+    const bool m_active = m0 + wm * 64 < a.Cm;
+    const GatherGeom g = a.g;
+    const int W = g.Wout, H = g.Hout, Cin = g.Ck, lw = g.lw, lhw = g.lhw;
+    const int RW = 32 >> lw, HC = W + 2, HP = (RW + 2) * HC;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
+    const long long x_bytes = (long long)g.img_pitch * 2 * (a.P >> lhw);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+    // DMA pieces exactly as in igemm_wgrad3x3_kernel: piece 0 = this wave's 4 rows of the dY tile, pieces 1, 2 = 8 halo pixels each
+    const int r_in = lane >> 4, ps = lane & 15;
+    const int c16 = ((((ps >> 1) ^ wg_swz(4 * wave + r_in)) << 1) | (ps & 1));
+    const int am = m0 + c16 * 8;
+    const bool a_ok = am < a.Cm;
+    int hb_hr[2], hb_off[2];
+    bool hb_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hp = 8 * (wave + 8 * i) + (lane >> 3);
+        const int lc = (lane & 7) ^ (halo_swz(hp) << 1);
+        const int hr = hp / HC, hc = hp - hr * HC;
+        hb_hr[i] = hr;
+        hb_ok[i] = hp < HP && (unsigned)(hc - 1) < (unsigned)W && ci0 + lc * 8 < Cin;
+        hb_off[i] = ((hc - 1) * Cin + ci0 + lc * 8) * 2;
+    }
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.P, p_begin + a.pix_per_split);
+    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
+    auto issue_piece = [&](int kt, int piece) {          // piece 0: dY rows, 1 / 2: halo pixels
+        uint16_t* sa = smem + (kt % NSTAGE) * W3_STAGE;
+        const int p0 = p_begin + kt * 32;
+        if (piece == 0) {
+            const int p = p0 + 4 * wave + r_in;
+            const uint32_t oa = (p < p_end && a_ok) ? (uint32_t)(p * a.Cm + am) * 2u : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)(sa + wave * 512), 16, oa, 0, 0, 0);
+        } else {
+            const int i = piece - 1;
+            const int n = p0 >> lhw, h_base = (p0 & ((1 << lhw) - 1)) >> lw;
+            const int h = h_base - 1 + hb_hr[i];
+            const bool ok = hb_ok[i] && (unsigned)h < (unsigned)H && p0 < p_end;
+            const uint32_t ob = ok ? (uint32_t)((int)((long long)n * g.img_pitch * 2) + h * (W * Cin * 2) + hb_off[i]) : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sa + W3_A_ELEMS + (wave + 8 * i) * 512), 16, ob, 0, 0, 0);
+        }
+    };
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int hrow_base = ((8 * gq) >> lw) * HC + ((8 * gq) & (W - 1)) + q;
+    int boff0[9], boff1[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int row0 = hrow_base + r * HC + s2, row1 = row0 + 4;
+            boff0[r * 3 + s2] = row0 * 64 + ((wn ^ halo_swz(row0)) << 4) + 4 * pp;
+            boff1[r * 3 + s2] = row1 * 64 + ((wn ^ halo_swz(row1)) << 4) + 4 * pp;
+        }
+    static_assert(NSTAGE >= 4 && NSTAGE <= 6, "ring depth");
+    constexpr int LEAD = NSTAGE - 3;                     // k-steps (3 pieces each) that may stay in flight at the barrier
+    auto wait_keep = [&](int n) {
+        if (n <= 0) dma_wait<0>();
+        else if (n == 1) dma_wait<3>();
+        else if (n == 2) dma_wait<6>();
+        else dma_wait<9>();
+    };
+    TrPair ra[4], rb[9];
+    if (ksteps > 0) {
+        int issued = 0;
+        for (; issued < NSTAGE && issued < ksteps; ++issued) { issue_piece(issued, 0); issue_piece(issued, 1); issue_piece(issued, 2); }
+        { const int keep = issued - 2; wait_keep(keep < 0 ? 0 : (keep > LEAD ? LEAD : keep)); }      // k-steps 0 and 1 have landed
+        __builtin_amdgcn_s_barrier();                              // P0
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
+        if (m_active) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = tr_frag_raw(smem, wm * 4 + i, lane);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rb[k] = TrPair{ds_read_tr_raw(smem + W3_A_ELEMS + boff0[k]), ds_read_tr_raw(smem + W3_A_ELEMS + boff1[k])};
+            tr_settle<0>(ra[0], ra[1], ra[2], ra[3]);
+            tr_settle<0>(rb[0], rb[1], rb[2], rb[3]);
+            tr_settle<0>(rb[4], rb[5], rb[6], rb[7]);
+            tr_settle_all(rb[8]);
+        }
+        int st = 1 % NSTAGE;                                       // stage of k-step t + 1
+        for (int t = 0; t < ksteps; ++t) {
+            const bool rd = t + 1 < ksteps, dma = t >= 1 && issued < ksteps;
+            const uint16_t* sa = smem + st * W3_STAGE;
+            const uint16_t* sb = sa + W3_A_ELEMS;
+            // multiplies of k-step t; behind tap k's MFMAs the two B requests of k-step t + 1 into the registers they have just read; the
+            // DMA pieces of k-step `issued` behind taps 2, 5 and 8; the A requests last (A is read by every tap: a second A set did not
+            // fit the 256 registers, so its eight reads return in the open, ~170 cycles of a ~1300-cycle k-step)
+            if (m_active) {
+                bf16x8_t fa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = tr_join(ra[i]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const bf16x8_t fb = tr_join(rb[k]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[k][i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);             // the requests below stay behind this tap's MFMAs (they overwrite rb[k])
+                    if (rd) rb[k] = TrPair{ds_read_tr_raw(sb + boff0[k]), ds_read_tr_raw(sb + boff1[k])};
+                    if (dma && (k == 2 || k == 5 || k == 8)) issue_piece(issued, k / 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (rd) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ra[i] = tr_frag_raw(sa, wm * 4 + i, lane);
+                    tr_settle<0>(ra[0], ra[1], ra[2], ra[3]);
+                    tr_settle<0>(rb[0], rb[1], rb[2], rb[3]);
+                    tr_settle<0>(rb[4], rb[5], rb[6], rb[7]);
+                    tr_settle_all(rb[8]);
+                }
+            } else if (dma) { issue_piece(issued, 0); issue_piece(issued, 1); issue_piece(issued, 2); }
+            if (dma) ++issued;
+            const int keep = issued - (t + 3);                     // k-step t + 2 has landed at E_t
+            wait_keep(keep < 0 ? 0 : (keep > LEAD ? LEAD : keep));
+            __builtin_amdgcn_s_barrier();                          // E_t
+            st = st + 1 == NSTAGE ? 0 : st + 1;
+        }
+    }
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
+    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
+    if (m_active)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int n = t * Cin + ci0 + wn * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
+                slab[(size_t)m * a.Ntot + n] = acc[t][i][rr];
+            }
+    }
+    if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
+    }
+}
+
 // wgrad, wave-grid variant: WM x WN waves of 64 x 64 sub-tiles; the (64*WM) x (64*WN) block tile is held as (TM+TN)/128
 // swizzled [32 px][128 ch] LDS images per stage (same image / tr-read scheme as above), NSTAGE-deep ring.
 template <int WM, int WN, int NSTAGE, bool COLSUM = false>
@@ -2774,8 +2940,20 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
         const int tm3 = (a.Cm + 127) / 128, tn3 = a.g.Ck / 64;
         const int lds = 3 * W3_STAGE * 2;            // 3 stages x 24 KiB (4 and 5 measured the same, before and after the inline-asm reads: the
                                                      // k-step is bound by its 26 transposing reads + 36 MFMAs per wave, two waves per SIMD)
-        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
-        hipLaunchKernelGGL(igemm_wgrad3x3_kernel<3>, dim3(((tm3 * tn3 * a.splits + 7) / 8) * 8), dim3(512), lds, st, args, tm3, tn3);
+        DALI_ONCE_PER_DEVICE({
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_p_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 5));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_p_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 6));
+        });
+        // DALI_WGRAD3X3_P: 0 (default) = the round-2 kernel, 5 / 6 = the software-pipelined kernel with that ring depth (A/B aid).  Measured,
+        // interleaved in one process: layer4 conv2 152 us (round 2) against 161 (pipelined) and 195 (ping-pong); layer2 / layer3 66 against 68.
+        // PMC on the round-2 kernel at the layer4 shape: matrix pipe busy 45 % of the SIMD cycles, LDS active 23 % (28 % of that bank
+        // conflicts), waves parked at s_waitcnt / barriers 26 % of their cycles: neither the issue order nor the LDS bounds it.
+        const int pm = DALI_ENV_INT("DALI_WGRAD3X3_P", 0);
+        const dim3 grid3(((tm3 * tn3 * a.splits + 7) / 8) * 8);
+        if (pm == 5) hipLaunchKernelGGL(igemm_wgrad3x3_p_kernel<5>, grid3, dim3(512), lds / 3 * 5, st, args, tm3, tn3);
+        else if (pm) hipLaunchKernelGGL(igemm_wgrad3x3_p_kernel<6>, grid3, dim3(512), lds / 3 * 6, st, args, tm3, tn3);
+        else hipLaunchKernelGGL(igemm_wgrad3x3_kernel<3>, grid3, dim3(512), lds, st, args, tm3, tn3);
     } else if (!a.in_scale && dma_ok && wcfg == 1) {
         const int tm2 = (a.Cm + 255) / 256, tn2 = (a.Ntot + 255) / 256;
         const int lds = 4 * 4 * 32 * 128 * 2;       // 4 stages x 4 images x 8 KiB
