@@ -665,6 +665,272 @@ int launch_colsum(hipStream_t st, const uint16_t* y, int rows, int C, float* out
     DALI_LAUNCH_CHECK();
     return launch_reduce_finish<1>(st, partial, blocks, C, scratch, FinStore{{out, nullptr, nullptr, nullptr}, 1});
 }
+// ------------------------------------------------------------------------------------------------
+// Attention, second form (round 3): the probabilities never leave the registers, and only the two operands EVERY wave needs live in LDS.
+//
+// An MFMA sums over 32 "slots" (lane group g = lane >> 4, position s = 0..7); which k index a slot means is free as long as the A and the B
+// operand agree.  The accumulator of a 16 x 16 tile leaves lane (g, i) with rows 4g .. 4g+3 of column i -- exactly four slots of lane group g
+// of an A operand whose row is i.  So a score tile computed TRANSPOSED (rows = keys, columns = queries: S^T = K Q^T) is, after the softmax,
+// already the A operand of P V for query row i, with slots (g, 0..3) = keys 16 j0 + 4g .. +3 of one key tile and slots (g, 4..7) = the same
+// keys of a second tile; the B operand takes the matching rows of V by two transposing reads (frag_tr2).  No per-wave strip in LDS, no
+// write / barrier / re-read of P (the first form spent more on those than on its MFMAs: 93 us forward, 317 us backward per layer for
+// 5 us and 11 us of matrix work per workgroup).  The same trick gives dQ = dS K from dS^T, and dV = P^T dO, dK = dS^T Q from the
+// UN-transposed tiles S = Q K^T, so the backward is two kernels: one workgroup per (batch, head) each, the query (key) tile a wave owns is
+// loaded straight from global memory as fragments, K and V (Q and dO) for all tiles sit in LDS: 60 KB, two workgroups per CU, so one loads
+// while the other computes.  S and dP are computed once per kernel (the first form computed S three times and dP twice).
+// ------------------------------------------------------------------------------------------------
+// 4 + 4 rows of one column per lane: rows rowA + 4g + (0..3) and rowB + 4g + (0..3), column n0 + (lane & 15)
+__device__ __forceinline__ bf16x8_t frag_tr2(const uint16_t* base, int ld, int rowA, int rowB, int n0, int lane) {
+    typedef __attribute__((address_space(3))) s16x4v* lp;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + (rowA + 4 * g + q) * ld + n0 + 4 * p));
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + (rowB + 4 * g + q) * ld + n0 + 4 * p));
+    const s16x8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// K-contiguous fragment straight from global memory: element (row0 + lane&15, k0 + 8*(lane>>4) .. +7), rows >= T are zero
+__device__ __forceinline__ bf16x8_t frag_g(const uint16_t* __restrict__ src, size_t row_stride, int row0, int k0, int T, int lane) {
+    const int row = row0 + (lane & 15);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < T) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + k0 + 8 * (lane >> 4));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t pack_frag(const float (&a)[4], const float (&b)[4]) {
+    const uint4 v = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int NTILE, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attention_fwd2_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
+                                                                    uint16_t* __restrict__ out, float* __restrict__ lse) {
+    constexpr int TP = NTILE * 16, NPAIR = (NTILE + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    uint16_t* sK = sm;
+    uint16_t* sV = sK + TP * ATT_LD;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t rs = (size_t)3 * C;
+    const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
+    att_load_tile<TP>(base + C, rs, T, sK);
+    att_load_tile<TP>(base + 2 * C, rs, T, sV);
+    __syncthreads();
+    const float sc2 = scale * 1.44269504088896f;                     // exp(x) = 2^(x log2 e)
+    for (int qt = wave; qt < NTILE; qt += NW) {
+        if (qt * 16 >= T) break;
+        const bf16x8_t qa0 = frag_g(base, rs, qt * 16, 0, T, lane), qa1 = frag_g(base, rs, qt * 16, 32, T, lane);
+        f32x4_t s[NTILE];
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) {
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, a, 0, 0, 0);
+            const int key0 = j * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (key0 + r < T) ? a[r] * sc2 : -__builtin_inff(); m = fmaxf(m, a[r]); }
+            s[j] = a;
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[j][r] = __builtin_amdgcn_exp2f(s[j][r] - m); l += s[j][r]; }
+        l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+        const float inv_l = 1.0f / l;
+        if (lane < 16) {
+            const int row = qt * 16 + lane;
+            if (row < T && lse) lse[(size_t)bh * T + row] = (m + log2f(l)) * 0.6931471805599453f;     // natural-log lse = max + log(sum)
+        }
+        f32x4_t o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int jp = 0; jp < NPAIR; ++jp) {
+            const int j0 = 2 * jp, j1 = 2 * jp + 1 < NTILE ? 2 * jp + 1 : j0;       // odd tile count: the last pair's second half is zero
+            float pa[4], pb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pa[r] = s[j0][r] * inv_l; pb[r] = 2 * jp + 1 < NTILE ? s[j1][r] * inv_l : 0.f; }
+            const bf16x8_t pf = pack_frag(pa, pb);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr2(sV, ATT_LD, j0 * 16, j1 * 16, d * 16, lane), o[d], 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = qt * 16 + (lane >> 4) * 4 + r;
+                if (row < T) out[((size_t)b * T + row) * C + h * ATT_HD + d * 16 + (lane & 15)] = f32_to_bf16_bits(o[d][r]);
+            }
+    }
+}
+
+// dQ: one wave per query tile, K and V of the head in LDS.  dS^T = P^T (dP^T - D) scale with P^T = exp(S^T scale - lse), dQ = dS K.
+template <int NTILE, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attention_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                                      const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                                      int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
+    constexpr int TP = NTILE * 16, NPAIR = (NTILE + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    uint16_t* sK = sm;
+    uint16_t* sV = sK + TP * ATT_LD;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t rs = (size_t)3 * C;
+    const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
+    const uint16_t* go = d_o + (size_t)b * T * C + h * ATT_HD;
+    const uint16_t* oo = o + (size_t)b * T * C + h * ATT_HD;
+    att_load_tile<TP>(base + C, rs, T, sK);
+    att_load_tile<TP>(base + 2 * C, rs, T, sV);
+    __syncthreads();
+    const float sc2 = scale * 1.44269504088896f;
+    uint16_t* dq_base = dqkv + (size_t)b * T * rs + h * ATT_HD;
+    for (int qt = wave; qt < NTILE; qt += NW) {
+        if (qt * 16 >= T) break;
+        const bf16x8_t qa0 = frag_g(base, rs, qt * 16, 0, T, lane), qa1 = frag_g(base, rs, qt * 16, 32, T, lane);
+        const bf16x8_t ga0 = frag_g(go, C, qt * 16, 0, T, lane), ga1 = frag_g(go, C, qt * 16, 32, T, lane);
+        // D_i = sum_d dO[i][d] O[i][d]: this lane's 16 of the 64 products (the d it holds of dO), then over the four lane groups
+        float di = 0.f;
+        {
+            const bf16x8_t oa0 = frag_g(oo, C, qt * 16, 0, T, lane), oa1 = frag_g(oo, C, qt * 16, 32, T, lane);
+            float a8[8], b8[8];
+            unpack8v(__builtin_bit_cast(uint4, ga0), a8); unpack8v(__builtin_bit_cast(uint4, oa0), b8);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) di += a8[t] * b8[t];
+            unpack8v(__builtin_bit_cast(uint4, ga1), a8); unpack8v(__builtin_bit_cast(uint4, oa1), b8);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) di += a8[t] * b8[t];
+            di += __shfl_xor(di, 16, 64); di += __shfl_xor(di, 32, 64);
+        }
+        const int qrow = qt * 16 + (lane & 15);
+        const float lq = (qrow < T ? lse[(size_t)bh * T + qrow] : 0.f) * 1.44269504088896f;
+        f32x4_t dq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int jp = 0; jp < NPAIR; ++jp) {
+            float v[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int j = 2 * jp + hh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[hh][r] = 0.f;
+                if (j < NTILE) {
+                    f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, sc, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 0, lane), ga0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 32, lane), ga1, dp, 0, 0, 0);
+                    const int key0 = j * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = (key0 + r < T) ? __builtin_amdgcn_exp2f(sc[r] * sc2 - lq) : 0.f;
+                        v[hh][r] = p * (dp[r] - di) * scale;
+                    }
+                }
+            }
+            const int j0 = 2 * jp, j1 = 2 * jp + 1 < NTILE ? 2 * jp + 1 : j0;
+            const bf16x8_t da = pack_frag(v[0], v[1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, frag_tr2(sK, ATT_LD, j0 * 16, j1 * 16, d * 16, lane), dq[d], 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = qt * 16 + (lane >> 4) * 4 + r;
+                if (row < T) dq_base[(size_t)row * rs + d * 16 + (lane & 15)] = f32_to_bf16_bits(dq[d][r]);
+            }
+    }
+}
+
+// dK, dV: one wave per key tile, Q and dO of the head (and lse, D) in LDS.  dV = P^T dO, dK = dS^T Q from the un-transposed tiles S = Q K^T.
+template <int NTILE, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attention_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                                       const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                                       int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
+    constexpr int TP = NTILE * 16, NPAIR = (NTILE + 1) / 2, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
+    uint16_t* sQ = sm;
+    uint16_t* sD = sQ + TP * ATT_LD;
+    float* sLse = reinterpret_cast<float*>(sD + TP * ATT_LD);      // [TP], already times log2 e
+    float* sDi = sLse + TP;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t rs = (size_t)3 * C;
+    const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
+    const uint16_t* go = d_o + (size_t)b * T * C + h * ATT_HD;
+    att_load_tile<TP>(base, rs, T, sQ);
+    att_load_tile<TP>(go, C, T, sD);
+    for (int i0 = 0; i0 < TP; i0 += NT / 8) {                        // D_i: 8 lanes x 16 bytes per row
+        const int i = i0 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+        float acc = 0.f;
+        if (i < T) {
+            float ov[8], gv[8];
+            unpack8v(*reinterpret_cast<const uint4*>(o + ((size_t)b * T + i) * C + h * ATT_HD + ch * 8), ov);
+            unpack8v(*reinterpret_cast<const uint4*>(go + (size_t)i * C + ch * 8), gv);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc += ov[d] * gv[d];
+        }
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (ch == 0 && i < TP) sDi[i] = acc;
+    }
+    for (int i = threadIdx.x; i < TP; i += NT) sLse[i] = (i < T) ? lse[(size_t)bh * T + i] * 1.44269504088896f : 0.f;
+    __syncthreads();
+    const float sc2 = scale * 1.44269504088896f;
+    uint16_t* dq_base = dqkv + (size_t)b * T * rs + h * ATT_HD;
+    for (int kt = wave; kt < NTILE; kt += NW) {
+        if (kt * 16 >= T) break;
+        const bf16x8_t ka0 = frag_g(base + C, rs, kt * 16, 0, T, lane), ka1 = frag_g(base + C, rs, kt * 16, 32, T, lane);
+        const bf16x8_t va0 = frag_g(base + 2 * C, rs, kt * 16, 0, T, lane), va1 = frag_g(base + 2 * C, rs, kt * 16, 32, T, lane);
+        f32x4_t dk[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4_t dv[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const bool key_ok = kt * 16 + (lane & 15) < T;
+#pragma unroll
+        for (int jp = 0; jp < NPAIR; ++jp) {
+            float pv[2][4], dsv[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int j = 2 * jp + hh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pv[hh][r] = 0.f; dsv[hh][r] = 0.f; }
+                if (j < NTILE) {
+                    // rows = queries of tile j, columns = this tile's keys: lane (g, i) holds queries 16 j + 4g .. +3 of key i
+                    f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 0, lane), ka0, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 32, lane), ka1, st, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 0, lane), va0, dpt, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 32, lane), va1, dpt, 0, 0, 0);
+                    const int q0 = j * 16 + (lane >> 4) * 4;
+                    const float4 lq4 = *reinterpret_cast<const float4*>(sLse + q0), dq4 = *reinterpret_cast<const float4*>(sDi + q0);
+                    const float lqv[4] = {lq4.x, lq4.y, lq4.z, lq4.w}, dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = (key_ok && q0 + r < T) ? __builtin_amdgcn_exp2f(st[r] * sc2 - lqv[r]) : 0.f;
+                        pv[hh][r] = p;
+                        dsv[hh][r] = p * (dpt[r] - dqv[r]) * scale;
+                    }
+                }
+            }
+            const int j0 = 2 * jp, j1 = 2 * jp + 1 < NTILE ? 2 * jp + 1 : j0;
+            const bf16x8_t pf = pack_frag(pv[0], pv[1]), df = pack_frag(dsv[0], dsv[1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr2(sD, ATT_LD, j0 * 16, j1 * 16, d * 16, lane), dv[d], 0, 0, 0);
+                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, frag_tr2(sQ, ATT_LD, j0 * 16, j1 * 16, d * 16, lane), dk[d], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + (lane >> 4) * 4 + r;
+                if (key < T) {
+                    dq_base[(size_t)key * rs + C + d * 16 + (lane & 15)] = f32_to_bf16_bits(dk[d][r]);
+                    dq_base[(size_t)key * rs + 2 * C + d * 16 + (lane & 15)] = f32_to_bf16_bits(dv[d][r]);
+                }
+            }
+    }
+}
+template <int NTILE> constexpr size_t att2_lds() { return (size_t)2 * NTILE * 16 * ATT_LD * 2 + 2 * NTILE * 16 * 4; }
+static_assert(2 * att2_lds<16>() <= 163840, "two attention workgroups per CU");
+
 template <int NTILE, int NW> constexpr size_t att_fwd_lds() {
     return ((size_t)2 * AttGeom<NTILE>::TP * ATT_LD + (size_t)AttGeom<NTILE>::PK * ATT_LD + NW * 16 * ATT_SW) * 2;
 }
@@ -691,7 +957,32 @@ static int att_bwd_launch(hipStream_t st, const uint16_t* qkv, const uint16_t* o
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
+template <int NTILE, int NW>
+static int att2_fwd_launch(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
+    constexpr size_t lds = att2_lds<NTILE>();
+    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd2_kernel<NTILE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attention_fwd2_kernel<NTILE, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, B, T, H, scale, out, lse);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+template <int NTILE, int NW>
+static int att2_bwd_launch(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
+                           float scale, uint16_t* dqkv) {
+    constexpr size_t lds = att2_lds<NTILE>();
+    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_dq_kernel<NTILE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_dkv_kernel<NTILE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attention_bwd_dq_kernel<NTILE, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    hipLaunchKernelGGL((attention_bwd_dkv_kernel<NTILE, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+// DALI_ATT_V1=1 (A/B aid): the first form (P through per-wave LDS strips, one workgroup per CU)
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
+    if (!DALI_ENV_INT("DALI_ATT_V1", 0)) {
+        if (T <= 208) return att2_fwd_launch<13, 7>(st, qkv, B, T, H, scale, out, lse);
+        if (T <= 224) return att2_fwd_launch<14, 7>(st, qkv, B, T, H, scale, out, lse);
+        if (T <= 256) return att2_fwd_launch<16, 8>(st, qkv, B, T, H, scale, out, lse);
+    }
     if (T <= 208) return att_fwd_launch<13, 13>(st, qkv, B, T, H, scale, out, lse);
     if (T <= 224) return att_fwd_launch<14, 14>(st, qkv, B, T, H, scale, out, lse);
     if (T <= 256) return att_fwd_launch<16, 12>(st, qkv, B, T, H, scale, out, lse);
@@ -700,6 +991,11 @@ int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int 
 }
 int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
                          float scale, uint16_t* dqkv) {
+    if (!DALI_ENV_INT("DALI_ATT_V1", 0)) {
+        if (T <= 208) return att2_bwd_launch<13, 7>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+        if (T <= 224) return att2_bwd_launch<14, 7>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+        if (T <= 256) return att2_bwd_launch<16, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    }
     if (T <= 208) return att_bwd_launch<13, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
     if (T <= 224) return att_bwd_launch<14, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
     if (T <= 256) return att_bwd_launch<16, 3>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
