@@ -15,6 +15,7 @@
 #include "gemm_tile.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace dali {
@@ -2502,12 +2503,10 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGra
 }
 
 // Split-K reduce: out[e] (+)= sum_k partial[k][e] in a fixed order (deterministic).  One block covers 64 float4 chunks (1 KiB contiguous
-// per slab); wave w of its WAVES waves sums slabs w, w + WAVES, ... with up to 16 independent 16-byte loads in flight per lane, then the
-// waves' partial sums are added in wave order through LDS.  WAVES is chosen per launch (launch_splitk_reduce) so that the launch has about
-// four waves per CU: stamps (round 3) showed the reduce behind a weight-gradient GEMM taking 24-32 us for 33 MB of slabs -- as long as the
-// GEMM's main loop -- because 16 waves per chunk column left each lane TWO loads (layer3's 1024 x 256 gradients, 32 slabs): 16 k waves
-// that each wait one memory round trip for 32 bytes, then meet at a barrier.  One wave per column with 16 loads in flight reads the same
-// bytes in two round trips.
+// per slab); wave w of its WAVES waves sums slabs w, w + WAVES, ... in batches of up to 16 independent 16-byte loads per lane, then the
+// waves' partial sums are added in wave order through LDS.  Round 3: in-kernel stamps showed the reduce behind a weight-gradient GEMM
+// taking 24-32 us for 33 MB of slabs, as long as the GEMM's main loop: the batch was written as "k < splits ? load : 0" per element,
+// which hipcc turns into a branch around every load with a wait behind it -- the loads ran one after the other.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                                   size_t elems, int splits, int accumulate) {
@@ -2517,17 +2516,24 @@ __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* 
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool vec = (elems & 3) == 0 && i4 + 3 < elems;      // slabs stay 16-byte aligned only then
     if (vec) {
+        // batches of 16, 8, 4, 2, 1 slabs, every load of a batch unconditional: a per-load "k < splits ? load : 0" made hipcc branch around
+        // each load and wait for it (MI355X guide, trap (c) of the projection-GEMM notes): 32 dependent round trips, 28-37 us per launch
         const float* base = partial + i4;
-        for (int k0 = w; k0 < splits; k0 += 16 * WAVES) {
-            float4 v[16];
+        int k = w;
+        auto batch = [&](auto nconst) {
+            constexpr int N = decltype(nconst)::value;
+            float4 v[N];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = k0 + u * WAVES;
-                v[u] = (k < splits) ? *reinterpret_cast<const float4*>(base + (size_t)k * elems) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int u = 0; u < N; ++u) v[u] = *reinterpret_cast<const float4*>(base + (size_t)(k + u * WAVES) * elems);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-        }
+            for (int u = 0; u < N; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            k += N * WAVES;
+        };
+        while (k + 15 * WAVES < splits) batch(std::integral_constant<int, 16>{});
+        if (k + 7 * WAVES < splits) batch(std::integral_constant<int, 8>{});
+        if (k + 3 * WAVES < splits) batch(std::integral_constant<int, 4>{});
+        if (k + WAVES < splits) batch(std::integral_constant<int, 2>{});
+        if (k < splits) batch(std::integral_constant<int, 1>{});
     } else if (i4 < elems) {
         float* sp = reinterpret_cast<float*>(&s);
         for (int k = w; k < splits; k += WAVES)
@@ -3018,10 +3024,13 @@ int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_
     const unsigned rblocks = (unsigned)((chunks + 63) / 64);
     // waves per chunk column: enough for ~1024 waves in the launch, at most 16, and at least 4 slabs per wave.  A function of (elems, splits)
     // only, so the summation order of a given weight gradient never changes from step to step.
-    int W = 1;
-    while (W < 16 && (size_t)rblocks * W < 1024 && splits >= 8 * W) W *= 2;
-    const int ov = DALI_ENV_INT("DALI_REDUCE_WAVES", 0);               // A/B aid: force 1 / 2 / 4 / 8 / 16; -1 = the round-2 rule
-    if (ov == -1) W = splits >= 32 ? 16 : (splits >= 2 ? 4 : 1);
+    // waves per chunk column: 16 from 32 slabs on, else 4.  (An adaptive rule -- about 1024 waves per launch, at least 4 slabs per wave --
+    // measured the same standalone and 0.1 - 0.2 ms per train step SLOWER in the step, DALI_REDUCE_WAVES=-2; what made the reduce slow
+    // was the serialised loads described in the kernel, not the wave count.)  A function of (elems, splits) only, so the summation order
+    // of a given weight gradient never changes from step to step.
+    int W = splits >= 32 ? 16 : (splits >= 2 ? 4 : 1);
+    const int ov = DALI_ENV_INT("DALI_REDUCE_WAVES", 0);               // A/B aid: force 1 / 2 / 4 / 8 / 16; -2 = the adaptive rule
+    if (ov == -2) { W = 1; while (W < 16 && (size_t)rblocks * W < 1024 && splits >= 8 * W) W *= 2; }
     else if (ov > 0) W = ov;
     switch (W) {
         case 1: hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, partial, out, elems, splits, accumulate); break;
