@@ -43,8 +43,8 @@ out.append("All kernels: %.1f GB/step; GEMM kernels %.1f GB/step.\n" % (pmc["all
 out.append(pmd)
 if os.path.exists(src + "/pmc_mfma.md"):
     out.append("\n## MFMA utilisation (PMC pass 5: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE`, 7 steps in the process)\n")
-    out.append("mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); cu_busy = 4 x SQ_BUSY_CU_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs); "
-               "`scripts/pmc_mfma.py`.\n")
+    out.append("mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) = share of the SIMD-cycles in which the matrix pipe executes "
+               "(16 counted cycles per `v_mfma_f32_16x16x32_bf16`); `scripts/pmc_mfma.py`.\n")
     out.append(open(src + "/pmc_mfma.md").read())
 open("profiles/%s_%s_kernel_stats.md" % (RND, name), "w").write("\n".join(out))
 print("wrote profiles/%s_%s_kernel_stats.md" % (RND, name))
