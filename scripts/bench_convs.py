@@ -6,8 +6,8 @@ from daliid_amd import ops_nn as nn
 bf16 = torch.bfloat16
 B = int(os.environ.get("B", "256"))
 from bench_convs_shapes import L          # (name, H, W, cin, cout, k, stride, count)
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=20):
+    fn(); fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
