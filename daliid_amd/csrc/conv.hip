@@ -1246,6 +1246,123 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with 64 -> 64 channels (layer1's conv2, forward and data gradient), halo reuse (round 3).
+// In the GEMM view a 256-pixel tile fetches 9 x 256 pixel rows of 128 bytes (one per tap) + 9 x 8 KB of weights = 369 KB through the
+// L2 -> LDS path, and that path (~50 GB/s per CU), not the 38.7 GFLOP, set the 74-78 us of these launches (0.3 of their HBM roof).  Here a
+// workgroup fetches the tile's halo patch ONCE, (256 / W + 2) x (W + 2) pixels x 128 bytes = 43.5 KB, and every tap's B fragments are reads
+// of that patch at a shifted pixel: 116 KB per tile.  The weights still stream one tap per k-step through a 3-stage ring (all nine are 72 KB:
+// with the patch they would not leave room for a second workgroup per CU).
+// Tile = 256 consecutive pixels = 256 / W whole rows of one image (W in {16, 32}, H * W a multiple of 256); 4 consumer waves of 64 x 64 and
+// 4 producer waves as in igemm_conv_k64s_kernel<1, 4, 4, .>; epilogue shared.  Patch image: [halo pixel][64 ch], 16-byte chunk ^ ((hp >> 1) & 7):
+// conflict-free b128 fragment reads when the fragment's first halo pixel is even, two-way for odd starts (no swizzle of this family is
+// conflict-free at every shift -- exhaustive search -- and the B reads are a third of the fragment reads).
+// mode 0: input pixel (h - 1 + kr, w - 1 + ks); mode 1 (data gradient, stride 1): (h + 1 - kr, w + 1 - ks): the same patch, taps mirrored.
+// ------------------------------------------------------------------------------------------------
+constexpr int HALO64_PX = 344;                           // >= (256 / W + 2) * (W + 2) for W = 16 (324), 32 (340); 43 DMA pieces of 8 pixels
+template <int NSTAGE>
+__global__ __launch_bounds__(512, 4) void igemm_conv_halo64_kernel(IGemmArgs a, int tiles_n) {
+    constexpr int TM = 64, TN = 256, NC = 4, NP = 4, NT = NC * 64, FM = 4, FN = 4;
+    constexpr int A_ELEMS = TM * 64, RING = NSTAGE * A_ELEMS, NPIECE = HALO64_PX / 8, PPW = (NPIECE + NP - 1) / NP;   // 43 pieces, 11 per producer
+    constexpr int AHEAD = NSTAGE - 1;
+    static_assert(NSTAGE == 3, "ring depth (the waits below count 2 weight pieces per producer and k-step)");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t* patch = smem + RING;
+    const int tn = blockIdx.x;
+    if (tn >= tiles_n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const GatherGeom g = a.g;
+    const int W = g.Wout, H = g.Hout, HC = W + 2, lw = g.lw, lhw = g.lhw;
+    const int TR = 256 >> lw, HP = (TR + 2) * HC;
+    const int p0 = tn * TN, n_img = p0 >> lhw, row0 = (p0 & ((1 << lhw) - 1)) >> lw;       // first pixel / image / first image row of the tile
+    constexpr int ktiles = 9;
+    if (wave >= NC) {
+        // ---------------- producers: the halo patch once, then one weight tap per k-step ----------------
+        const int pw = wave - NC;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, 64 * 576 * 2, 0x00020000);
+        const long long x_bytes = (long long)g.img_pitch * 2 * (a.P >> lhw);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+        const int img_base = (int)((long long)n_img * g.img_pitch);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = pw + NP * i;                              // piece: halo pixels 8q .. 8q + 7
+            if (q < NPIECE) {
+                const int hp = 8 * q + (lane >> 3);
+                const int lc = (lane & 7) ^ ((hp >> 1) & 7);        // logical chunk stored in this lane's physical slot
+                const int hr = hp / HC, hc = hp - hr * HC;
+                const int ih = row0 - 1 + hr, iw = hc - 1;
+                const bool ok = hp < HP && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const uint32_t off = ok ? (uint32_t)(img_base + (ih * W + iw) * 64 + lc * 8) * 2u : DMA_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(patch + q * 512), 16, off, 0, 0, 0);
+            }
+        }
+        // weight tap kt: rows m = 8 (pw + 4 i) + lane >> 3 of the [64][64] stage image, k-tile-64 swizzle (see igemm_conv_k64_kernel)
+        const int r_in = lane >> 3;
+        const int kc = (lane & 7) ^ (((pw & 1) << 2) | (r_in >> 1));
+        uint32_t a_off[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_off[i] = (uint32_t)((8 * (pw + NP * i) + r_in) * 576 + kc * 8) * 2u;
+        auto issue_w = [&](int kt) {
+            uint16_t* sa = smem + (kt % NSTAGE) * A_ELEMS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t off = a_off[i] + (uint32_t)(kt * 128);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (pw + NP * i) * 512), 16, off, 0, 0, 0);
+            }
+        };
+        issue_w(0); issue_w(1);
+        dma_wait<2>();                                             // the patch and tap 0 have landed (tap 1 may be in flight)
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            if (kt + AHEAD < ktiles) { issue_w(kt + AHEAD); dma_wait<2>(); } else dma_wait<0>();     // tap kt + 1 has landed
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // ---------------- consumers: wave wn owns all 64 output channels of pixels 64 wn .. 64 wn + 63 ----------------
+    const int wn = wave;
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);       // weights: as igemm_conv_k64s_kernel
+    int hp_base[FN];                                               // halo pixel of tap (0, 0) [mode 0] for this lane's pixel of fragment j
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int p = wn * 64 + j * 16 + (lane & 15);
+        hp_base[j] = (p >> lw) * HC + (p & (W - 1));
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const uint16_t* sa = smem + (kt % NSTAGE) * A_ELEMS;
+        const int kr = kt / 3, ks = kt - 3 * kr;
+        const int tap_off = g.mode == 0 ? kr * HC + ks : (2 - kr) * HC + (2 - ks);
+        uint32_t boff[FN];                                         // element offset of the first k half of this lane's B fragment
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int hp = hp_base[j] + tap_off;
+            boff[j] = (uint32_t)(hp * 64 + (((lane >> 4) ^ ((hp >> 1) & 7)) << 3));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8_t fa[FM];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + (i * 16) * 64 + (frag_off ^ (h << 5)));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(patch + (boff[j] ^ (uint32_t)(h << 5)));
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of this weight stage are complete before it can be refilled
+        __builtin_amdgcn_s_barrier();
+    }
+    conv_epilogue_g<TM, TN, FM, FN, 4, NT, 2>(a, acc, 0, tn, smem, 0, wn);
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: M = Cm (channels of dY), N = R*S*Ck, K = pixels.  Both operands are stored pixel-major, so the
 // MFMA fragments (8 consecutive k per lane) are produced by ds_read_b64_tr_b16 transposing reads.
 // LDS image per operand and stage: [32 pixels][128 channels] bf16 (256-byte rows); the 32-byte chunk index is
@@ -2807,6 +2924,14 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         });
         if (k64 == 3) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 2, st, args, tiles_m, tiles_n);
+    } else if (narrow_k64 == 2 && a.Cm == 64 && a.g.Ck == 64 && a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && !a.g.sub && !lin &&
+               (a.g.Wout == 16 || a.g.Wout == 32) && args.g.lhw >= 8 && a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == 64 &&
+               a.g.row_pitch == a.g.Win * 64 && a.g.img_pitch == (long long)a.g.Hin * a.g.Win * 64 && a.P % 256 == 0 && DALI_ENV_INT("DALI_CONV_HALO64", 1)) {
+        // layer1's 3x3 (64 -> 64): the halo patch of a 256-pixel tile fetched once, taps read it at shifted pixels (igemm_conv_halo64_kernel)
+        const int lds = (3 * 64 * 64 + HALO64_PX * 64) * 2;
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_halo64_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+        const int tiles_n = a.P / 256;
+        hipLaunchKernelGGL((igemm_conv_halo64_kernel<3>), dim3(tiles_n), dim3(512), lds, st, args, tiles_n);
     } else if (narrow_k64 == 2) {
         // layer1's 3x3 (Cm = Cin = 64, K = 576): k-tile 64 = one full line per pixel and tap, 4 MFMA waves + 4 DMA waves, 2-stage ring,
         // two workgroups per CU: 94 -> 77 us forward, 90 -> 73 us data gradient (unspecialised k-tile 64: 84 / 79; 3-stage ring, one

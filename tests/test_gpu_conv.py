@@ -33,6 +33,8 @@ CASES = [
     (17, 31, 33, 1088, 320, 1, 1, 1, 0),  # ragged P = 17391, Cm = 320 (2.5 tiles), K = 17 x 64: specialised fwd + wgrad, zero-filled tails
     (17, 31, 33, 1088, 576, 1, 1, 1, 0),  # ragged 256x256 k-tile 64 fwd (2.25 tiles); dgrad K = 576: k-tile 32 128x256 kernel
     (128, 32, 16, 256, 256, 3, 3, 2, 1),  # layer3 conv2 (stride 2) at full pixel count: parity-split dgrad, its 4-tap class on the specialised kernel
+    (2, 16, 16, 64, 64, 3, 3, 1, 1),      # 64 -> 64 3x3 on the halo-patch kernel (igemm_conv_halo64_kernel): one 256-pixel tile per image, W = 16
+    (3, 64, 32, 64, 64, 3, 3, 1, 1),      # layer1 conv2's geometry (64 x 32 images, 8 tiles each): forward and data gradient on the halo-patch kernel
 ]
 
 
