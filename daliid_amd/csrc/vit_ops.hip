@@ -163,16 +163,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
     // rows load -> reduce -> store one after the other exposed one memory round trip per row: 56 us for 116 MB).
     uint4 ng[NCH], nx[NCH], na[NCH];
     float nmu = 0.f, nrs = 0.f;
+    // every load of a request is unconditional (lanes past C re-read column 0, an absent operand re-reads x: the values are never used):
+    // "if (c < C) { if (!g32) load; load; if (add) load; }" compiled to a branch and a wait around each load, six dependent round trips per
+    // row (47 us for 155 MB of traffic; MI355X guide, the per-element select trap)
+    const uint16_t* gsrc = g32 ? x : g;
+    const uint16_t* asrc = add ? add : x;
     auto request = [&](int row) {
         nmu = mean[row]; nrs = rstd[row];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = (lane + k * 64) * 8;
-            if (c < C) {
-                if (!g32) ng[k] = *reinterpret_cast<const uint4*>(g + (size_t)row * C + c);
-                nx[k] = *reinterpret_cast<const uint4*>(x + (size_t)row * C + c);
-                if (add) na[k] = *reinterpret_cast<const uint4*>(add + (size_t)row * C + c);
-            }
+            const size_t o = (size_t)row * C + (c < C ? c : 0);
+            ng[k] = *reinterpret_cast<const uint4*>(gsrc + o);
+            nx[k] = *reinterpret_cast<const uint4*>(x + o);
+            na[k] = *reinterpret_cast<const uint4*>(asrc + o);
         }
     };
     if (r0 + wave < r1) request(r0 + wave);
