@@ -378,6 +378,14 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 else return gbase + (size_t)q * a.Cm * 2;
             };
             if (a.Res) {                                        // residual tile -> LDS with 16-byte loads, same layout as the output
+                unsigned rm[ITERS];                             // (mask bytes requested together: see the fused output stage below)
+                if (a.res_mask) {
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int lp = lp0 + it * (NT / CPR);
+                        rm[it] = a.res_mask[row_bytes((lp / WROWS) * (FN_ * 16) + (lp % WROWS)) >> 4];
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
                     const int lp = lp0 + it * (NT / CPR);
@@ -385,7 +393,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     const size_t rb = row_bytes(q);
                     uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
                     if (a.res_mask) {                           // 16 bytes = 8 channels = one mask byte
-                        const unsigned m = a.res_mask[rb >> 4];
+                        const unsigned m = rm[it];
                         rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
                     }
                     *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) = rv;
@@ -524,11 +532,21 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         const int ch = threadIdx.x % CPR, lp0 = threadIdx.x / CPR;
         float4 sc4[Cfg::FM], sh4[Cfg::FM];
 #pragma unroll
-        for (int i = 0; i < Cfg::FM; ++i) {
-            const int c = tm * TM + mb + i * 16;
-            sc4[i] = a.out_scale ? *reinterpret_cast<const float4*>(a.out_scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-            sh4[i] = a.out_shift ? *reinterpret_cast<const float4*>(a.out_shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + c); sh4[i].x += b.x; sh4[i].y += b.y; sh4[i].z += b.z; sh4[i].w += b.w; }
+        for (int i = 0; i < Cfg::FM; ++i) { sc4[i] = make_float4(1.f, 1.f, 1.f, 1.f); sh4[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (a.out_scale) {                                      // one branch per batch of loads (as for the mask bytes below)
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i) sc4[i] = *reinterpret_cast<const float4*>(a.out_scale + tm * TM + mb + i * 16);
+        }
+        if (a.out_shift) {
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i) sh4[i] = *reinterpret_cast<const float4*>(a.out_shift + tm * TM + mb + i * 16);
+        }
+        if (a.bias) {
+            float4 bi4[Cfg::FM];
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i) bi4[i] = *reinterpret_cast<const float4*>(a.bias + tm * TM + mb + i * 16);
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i) { sh4[i].x += bi4[i].x; sh4[i].y += bi4[i].y; sh4[i].z += bi4[i].z; sh4[i].w += bi4[i].w; }
         }
         // the residual tile of BOTH halves is requested up front: the second half's loads fly while the first half is formed and stored
         // (requested per half they exposed one HBM round trip per half: these kernels are short-K, their epilogue is most of their time)
@@ -549,6 +567,23 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;     // bytes; + pixel q * Cm * 2
+            // the mask bytes of this half, requested together and early: "if (mask) m = mask[..]" inside the unrolled loops below compiled to a
+            // branch and a wait around every byte load (up to 16 dependent round trips per tile; MI355X guide, the per-element select trap)
+            unsigned om[ITERS], rm[ITERS];
+            if (a.out_mask) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lp = lp0 + it * (NT / CPR);
+                    om[it] = a.out_mask[(gbase + (size_t)((lp / WROWS) * (FN_ * 16) + (lp % WROWS)) * a.Cm * 2) >> 4];
+                }
+            }
+            if (a.Res && a.res_mask) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lp = lp0 + it * (NT / CPR);
+                    rm[it] = a.res_mask[(gbase + (size_t)((lp / WROWS) * (FN_ * 16) + (lp % WROWS)) * a.Cm * 2) >> 4];
+                }
+            }
             if (a.Res) {
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
@@ -559,7 +594,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     if constexpr (PRE) rv = rpre[h][it];
                     else rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
                     if (a.res_mask) {
-                        const unsigned m = a.res_mask[rb >> 4];
+                        const unsigned m = rm[it];
                         rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
                     }
                     *reinterpret_cast<uint4*>(stage + lp * ROWB + ch * 16) = rv;
@@ -577,7 +612,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
                     if (a.Res) {
                         const uint2 rv = *slot;
-                        if (a.res_scale) {                      // (loaded per use: L1-resident, and no registers held across the tile)
+                        if (a.res_scale) {                      // (loaded per use: L1-resident; held across the tile it cost 16 registers and spills)
                             const float4 rs = *reinterpret_cast<const float4*>(a.res_scale + tm * TM + mb + i * 16);
                             v0 += rs.x * bf16_bits_to_f32(rv.x & 0xffffu); v1 += rs.y * bf16_bits_to_f32(rv.x >> 16);
                             v2 += rs.z * bf16_bits_to_f32(rv.y & 0xffffu); v3 += rs.w * bf16_bits_to_f32(rv.y >> 16);
@@ -598,7 +633,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 const size_t ob = gbase + (size_t)q * a.Cm * 2;
                 uint4 v = *reinterpret_cast<const uint4*>(stage + lp * ROWB + ch * 16);
                 if (a.out_mask) {
-                    const unsigned m = a.out_mask[ob >> 4];
+                    const unsigned m = om[it];
                     v.x = gate_bf16x2(v.x, m); v.y = gate_bf16x2(v.y, m >> 2); v.z = gate_bf16x2(v.z, m >> 4); v.w = gate_bf16x2(v.w, m >> 6);
                 }
                 *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O) + ob) = v;
