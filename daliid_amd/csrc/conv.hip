@@ -2665,20 +2665,24 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGra
 
 // Split-K reduce: out[e] (+)= sum_k partial[k][e] in a fixed order (deterministic).  One block covers 64 float4 chunks (1 KiB contiguous
 // per slab); wave w of its WAVES waves sums slabs w, w + WAVES, ... in batches of up to 16 independent 16-byte loads per lane, then the
-// waves' partial sums are added in wave order through LDS.  Round 3: in-kernel stamps showed the reduce behind a weight-gradient GEMM
-// taking 24-32 us for 33 MB of slabs, as long as the GEMM's main loop: the batch was written as "k < splits ? load : 0" per element,
-// which hipcc turns into a branch around every load with a wait behind it -- the loads ran one after the other.
+// waves' partial sums are added in wave order through LDS.  Two round-3 findings, both from timing the launch alone
+// (scripts/bench_reduce.py, scripts/micro/bench_reduce.hip):
+// (1) the batch was written as "k < splits ? load : 0" per element, which hipcc turns into a branch around every load with a wait behind
+//     it -- the loads ran one after the other;
+// (2) the kernel also held the scalar path for element counts that are not a multiple of 4, which indexed the accumulator through a pointer
+//     (sp[e - i4]).  That made the accumulator an array: hipcc moved it to LDS (alloca promotion), indexed by the flattened thread id, whose
+//     computation reads the workgroup size from the DISPATCH PACKET (host memory) at the start of every wave.  The path never ran at the plan's
+//     shapes and cost them 30 us per launch whatever the wave count (3.5-13 us without it: 34 MB, resp. 76 MB, of slabs).  The odd sizes
+//     have their own kernel now; check new kernels for ".amdhsa_user_sgpr_dispatch_ptr 1".
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                  size_t elems, int splits, int accumulate) {
-    __shared__ float4 red[WAVES * 64];
+                                                                  size_t elems, int splits, int accumulate) {      // elems % 4 == 0
+    __shared__ float4 red[WAVES > 1 ? WAVES * 64 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t i4 = ((size_t)blockIdx.x * 64 + lane) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool vec = (elems & 3) == 0 && i4 + 3 < elems;      // slabs stay 16-byte aligned only then
-    if (vec) {
-        // batches of 16, 8, 4, 2, 1 slabs, every load of a batch unconditional: a per-load "k < splits ? load : 0" made hipcc branch around
-        // each load and wait for it (MI355X guide, trap (c) of the projection-GEMM notes): 32 dependent round trips, 28-37 us per launch
+    const bool in = i4 < elems;
+    if (in) {
         const float* base = partial + i4;
         int k = w;
         auto batch = [&](auto nconst) {
@@ -2695,10 +2699,6 @@ __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* 
         if (k + 3 * WAVES < splits) batch(std::integral_constant<int, 4>{});
         if (k + WAVES < splits) batch(std::integral_constant<int, 2>{});
         if (k < splits) batch(std::integral_constant<int, 1>{});
-    } else if (i4 < elems) {
-        float* sp = reinterpret_cast<float*>(&s);
-        for (int k = w; k < splits; k += WAVES)
-            for (size_t e = i4; e < elems; ++e) sp[e - i4] += partial[(size_t)k * elems + e];
     }
     if (WAVES > 1) {
         red[threadIdx.x] = s;
@@ -2706,16 +2706,26 @@ __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* 
         if (w == 0)
             for (int k = 1; k < WAVES; ++k) { const float4 v = red[k * 64 + lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     }
-    if (w == 0 && i4 < elems) {
-        if (vec) {
-            float4* o = reinterpret_cast<float4*>(out + i4);
-            if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
-            *o = s;
-        } else {
-            const float* sp = reinterpret_cast<const float*>(&s);
-            for (int t = 0; t < 4 && i4 + t < elems; ++t) out[i4 + t] = accumulate ? out[i4 + t] + sp[t] : sp[t];
-        }
+    if (w == 0 && in) {
+        float4* o = reinterpret_cast<float4*>(out + i4);
+        if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+        *o = s;
     }
+}
+
+// The same sum for element counts that are not a multiple of 4 (slabs are not 16-byte aligned then: bias gradients of odd widths), one
+// element per lane, the same order of additions as the kernel above with `waves` waves (wave partial sums, then wave order).
+__global__ __launch_bounds__(256) void splitk_reduce_odd_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t elems,
+                                                                int splits, int accumulate, int waves) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    float s = 0.f;
+    for (int w = 0; w < waves; ++w) {
+        float p = 0.f;
+        for (int k = w; k < splits; k += waves) p += partial[(size_t)k * elems + e];
+        s = w ? s + p : p;
+    }
+    out[e] = accumulate ? out[e] + s : s;
 }
 
 static inline int ilog2_exact(int v) {
@@ -3201,6 +3211,11 @@ int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_
     const int ov = DALI_ENV_INT("DALI_REDUCE_WAVES", 0);               // A/B aid: force 1 / 2 / 4 / 8 / 16; -2 = the adaptive rule
     if (ov == -2) { W = 1; while (W < 16 && (size_t)rblocks * W < 1024 && splits >= 8 * W) W *= 2; }
     else if (ov > 0) W = ov;
+    if (elems & 3) {
+        hipLaunchKernelGGL(splitk_reduce_odd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, out, elems, splits, accumulate, W);
+        DALI_LAUNCH_CHECK();
+        return DALI_OK;
+    }
     switch (W) {
         case 1: hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, partial, out, elems, splits, accumulate); break;
         case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(rblocks), dim3(128), 0, st, partial, out, elems, splits, accumulate); break;
@@ -3217,6 +3232,15 @@ int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_
 // Diagnostic (not in include/daliid.h): device buffer of 4 x uint64 per block that the LDS-DMA conv kernel fills with
 // s_memrealtime stamps (100 MHz); null switches it off.  scripts/conv_block_timeline.py reads it.
 extern "C" int dali_debug_set_conv_stamps(void* dev_ptr) { g_conv_stamps = static_cast<unsigned long long*>(dev_ptr); return DALI_OK; }
+// Diagnostics for scripts/bench_reduce.py (not in include/daliid.h): the split count wgrad_plan picks, and the reduce alone.
+extern "C" int dali_debug_wgrad_splits(int Cm, int Ntot, int P, int taps, int halo_w) {
+    int sp = 0, pps = 0; size_t wsb = 0;
+    wgrad_plan(Cm, Ntot, P, 512, &sp, &pps, &wsb, taps, halo_w);
+    return sp;
+}
+extern "C" int dali_debug_splitk_reduce(void* stream, const float* partial, float* out, long long elems, int splits, int accumulate) {
+    return launch_splitk_reduce(static_cast<hipStream_t>(stream), partial, out, (size_t)elems, splits, accumulate);
+}
 
 extern "C" int dali_gemm_profile_begin(dali_ctx* ctx, int max_launches) {
     DALI_REQUIRE(ctx && max_launches > 0, "dali_gemm_profile_begin: bad argument");

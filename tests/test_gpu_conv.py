@@ -137,3 +137,23 @@ def test_conv_fused_bn_relu_operand(nn, case):
     dw = nn.conv2d_wgrad(x.cuda(), dy.cuda(), (r, s), stride, pad, in_scale=scale.cuda(), in_shift=shift.cuda(), in_relu=True)
     ref_dw = wref.grad.permute(0, 2, 3, 1)
     np.testing.assert_allclose(dw.cpu().numpy(), ref_dw.numpy(), rtol=2e-4, atol=2e-3 * float(ref_dw.abs().max()))
+
+
+@pytest.mark.parametrize("elems,splits,accumulate", [(4096, 512, 0), (262144, 32, 0), (65536, 7, 1), (1024 * 9 + 4, 33, 0), (751, 16, 0), (751, 41, 1),
+                                                     (2050, 3, 0), (5, 130, 1), (1048576, 8, 0)])
+def test_splitk_reduce_alone(nn, elems, splits, accumulate):
+    """The split-K reduce by itself (dali_debug_splitk_reduce), incl. element counts that are not a multiple of 4 (their own kernel): integer
+    slabs make every order of additions exact, so the result must EQUAL the fp64 column sum."""
+    import ctypes
+    from daliid_amd import _lib
+    lib = _lib.lib()
+    lib.dali_debug_splitk_reduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+    gen = torch.Generator().manual_seed(elems + splits)
+    slabs = torch.randint(-8, 9, (splits, elems), generator=gen).float().cuda()
+    out = torch.randint(-8, 9, (elems + 8,), generator=gen).float().cuda()                # 8 guard elements behind the result
+    before = out.clone()
+    rc = lib.dali_debug_splitk_reduce(torch.cuda.current_stream().cuda_stream, slabs.data_ptr(), out.data_ptr(), elems, splits, accumulate)
+    assert rc == 0
+    ref = slabs.double().sum(0) + (before[:elems].double() if accumulate else 0)
+    assert torch.equal(out[:elems].double(), ref)
+    assert torch.equal(out[elems:], before[elems:])
