@@ -21,8 +21,9 @@ out.append("Produced by `bash scripts/profile_train.sh %s` on an MI355X box: (1)
 out.append("Bench line of run (1) (unprofiled):\n\n```\n%s\n```\n" % bench_full)
 out.append("Bench line of run (2) (under rocprofv3):\n\n```\n%s\n```\n" % bench)
 out.append("## Per-kernel summary of run (2) (%d steps in the process: 3 warm-up + 10 timed + 3 event-bracketed)\n" % steps)
-out.append("Note: rocprofv3 attributes ~20 us of a long kernel's tail to a short kernel that follows it (the split-K reduce after a wgrad kernel "
-           "reads 23-35 us here but 1-6 us between HIP events in isolation, `scripts/micro/bench_reduce.hip`); sums over a step are unaffected.\n")
+out.append("Note (round 3): up to round 2 this table showed the split-K reduce at 21-33 us per launch and a note here blamed rocprofv3's attribution "
+           "(the micro-benchmark of the reduce measured 1-6 us).  The profile was right: the library kernel carried a scalar path the micro-benchmark "
+           "lacked, which made every wave read the dispatch packet (DESIGN.md section 6); fixed in round 3.\n")
 out.append("| kernel | calls | total ms | ms/step | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|---:|")
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
 for r in rows[:40]:
