@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
+#include <string>
+#include <cstdio>
 
 namespace dali {
 
@@ -2797,15 +2799,16 @@ struct GemmProfiler {
     std::vector<hipEvent_t> ev;        // 2 per launch
     std::vector<int> cls;
     std::vector<double> flops;
+    std::vector<std::string> desc;     // one line per launch for DALI_GEMM_PROFILE_DUMP
     size_t used = 0, cap = 0;
 };
 static GemmProfiler* g_prof = nullptr;
 struct ProfScope {
     hipStream_t st; bool on = false; size_t i = 0;
-    ProfScope(hipStream_t s, int cls, double flops) : st(s) {
+    ProfScope(hipStream_t s, int cls, double flops, const char* what = "") : st(s) {
         if (!g_prof || g_prof->used >= g_prof->cap) return;
         on = true; i = g_prof->used++;
-        g_prof->cls[i] = cls; g_prof->flops[i] = flops;
+        g_prof->cls[i] = cls; g_prof->flops[i] = flops; g_prof->desc[i] = what;
         (void)hipEventRecord(g_prof->ev[2 * i], st);
     }
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof->ev[2 * i + 1], st); }
@@ -2888,7 +2891,12 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         return DALI_ERR_LIMIT;
     }
     {
-    ProfScope prof_scope(st, 0, a.g.sub == 2 ? 2.0 * a.Cm * (double)a.P * a.g.R * a.g.S * a.g.Ck : 2.0 * a.Cm * (double)a.P * K);
+    char what[160] = "";
+    if (g_prof)
+        snprintf(what, sizeof what, "%s,Cm=%d,K=%d,P=%d,taps=%d,stride=%d,sub=%d,fused=%d,stats=%d,res=%d,mask=%d,lin=%d", a.g.mode ? "dgrad" : "fwd", a.Cm, K, a.P,
+                 a.g.R * a.g.S, a.g.stride, a.g.sub, a.out_scale ? 1 : 0, a.stats ? 1 : 0, a.Res ? 1 : 0, (a.res_mask || a.out_mask) ? 1 : 0,
+                 (a.bias || a.row_scale || a.act) ? 1 : 0);
+    ProfScope prof_scope(st, 0, a.g.sub == 2 ? 2.0 * a.Cm * (double)a.P * a.g.R * a.g.S * a.g.Ck : 2.0 * a.Cm * (double)a.P * K, what);
     // k-tile 64 pays where the main loop dominates (K >= 1024); with a short K or the 128 x 128 tile the smaller k-tile's 2-3
     // co-resident workgroups overlap their epilogues better (measured per layer: 256 x 256 -12..-15 %; 128 x 256 wave-specialised
     // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
@@ -3113,7 +3121,11 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     const long long x_bytes = (long long)a.g.img_pitch * 2 * ((a.P + a.g.Hout * a.g.Wout - 1) / (a.g.Hout * a.g.Wout));
     const bool dma_ok = x_bytes < 0x7ff00000ll && (long long)a.P * a.Cm * 2 < 0x7ff00000ll;
     {
-    ProfScope prof_scope(st, 1, 2.0 * a.Cm * (double)a.Ntot * a.P);
+    char what[160] = "";
+    if (g_prof)
+        snprintf(what, sizeof what, "wgrad,Cm=%d,K=%d,P=%d,taps=%d,stride=%d,sub=0,fused=%d,stats=0,res=0,mask=0,lin=%d", a.Cm, a.Ntot, a.P, a.g.R * a.g.S, a.g.stride,
+                 a.in_scale ? 1 : 0, a.colsum ? 1 : 0);
+    ProfScope prof_scope(st, 1, 2.0 * a.Cm * (double)a.Ntot * a.P, what);
     const bool halo_ok = a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && a.g.mode == 0 && args.g.lw >= 0 && args.g.lhw >= 7 &&
                          a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck;
     const int wcfg = wgrad_pick_cfg(a.Cm, a.Ntot, a.g.R * a.g.S, a.P, halo_ok ? a.g.Wout : 0);
@@ -3247,7 +3259,7 @@ extern "C" int dali_gemm_profile_begin(dali_ctx* ctx, int max_launches) {
     DALI_REQUIRE(!g_prof, "dali_gemm_profile_begin: a profile is already open");
     GemmProfiler* p = new GemmProfiler();
     p->cap = (size_t)max_launches;
-    p->ev.resize(2 * p->cap); p->cls.resize(p->cap); p->flops.resize(p->cap);
+    p->ev.resize(2 * p->cap); p->cls.resize(p->cap); p->flops.resize(p->cap); p->desc.resize(p->cap);
     for (auto& e : p->ev) DALI_HIP(hipEventCreate(&e));
     g_prof = p;
     return DALI_OK;
@@ -3260,13 +3272,17 @@ extern "C" int dali_gemm_profile_end(dali_ctx* ctx, double* total_ms, double* to
     g_prof = nullptr;
     for (int c = 0; c < 2; ++c) { total_ms[c] = 0; total_flops[c] = 0; launches[c] = 0; }
     int rc = DALI_OK;
+    const char* dump_path = getenv("DALI_GEMM_PROFILE_DUMP");          // development aid: one CSV line per launch (scripts/gemm_launch_table.py)
+    FILE* dump = dump_path ? fopen(dump_path, "a") : nullptr;
     for (size_t i = 0; i < p->used; ++i) {
         float ms = 0.f;
         if (hipEventSynchronize(p->ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]) != hipSuccess) {
             set_error("gemm_profile_end: event query failed"); rc = DALI_ERR_HIP; break;
         }
         total_ms[p->cls[i]] += ms; total_flops[p->cls[i]] += p->flops[i]; launches[p->cls[i]] += 1;
+        if (dump) fprintf(dump, "%zu,%s,us=%.2f,gflop=%.3f\n", i, p->desc[i].c_str(), ms * 1e3, p->flops[i] * 1e-9);
     }
+    if (dump) fclose(dump);
     for (auto& e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return rc;
