@@ -138,8 +138,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const uint16_t* __re
 // dgamma = sum_rows g*xhat and dbeta = sum_rows g   ->  partial[block][C][2]
 // NCH = 16-byte chunks per lane (C <= 512 NCH): the per-lane arrays are sized for the actual width (ViT-B: 2), not for the 2048 maximum
 // (160 of ~200 VGPRs were dead weight and held the kernel to 2 waves per SIMD)
-template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
+// MINW = waves per SIMD the register allocation must leave room for: at 173 VGPRs (the 256-thread default bound) two workgroups fit a CU and
+// the 768-workgroup launch sized for "three per CU in one round" ran as one and a half rounds
+template <int NCH, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void layernorm_bwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const uint16_t* __restrict__ add,
                                                              int rows, int C, int rows_per_block, uint16_t* __restrict__ dx,
@@ -159,47 +161,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
 #pragma unroll
         for (int t = 0; t < 8; ++t) gam[k][t] = (c < C) ? gamma[c + t] : 0.f;
     }
-    // One row per wave and iteration; the NEXT row's g / x / add chunks are requested before this row's arithmetic (a wave walking its 9
-    // rows load -> reduce -> store one after the other exposed one memory round trip per row: 56 us for 116 MB).
-    uint4 ng[NCH], nx[NCH], na[NCH];
-    float nmu = 0.f, nrs = 0.f;
-    // every load of a request is unconditional (lanes past C re-read column 0, an absent operand re-reads x: the values are never used):
-    // "if (c < C) { if (!g32) load; load; if (add) load; }" compiled to a branch and a wait around each load, six dependent round trips per
-    // row (47 us for 155 MB of traffic; MI355X guide, the per-element select trap)
+    // One row per wave and step, TWO rows of requests ahead (register sets A and B, the loop is unrolled by two): a wave walking its 9 rows
+    // load -> reduce -> store one after the other exposed one memory round trip per row (56 us for 116 MB); one row ahead still left the
+    // kernel latency-bound (8 waves per CU x 4.6 KB in flight = 3.8 TB/s by Little's law, measured 3.4).  Every load of a request is
+    // unconditional (lanes past C re-read column 0, an absent operand re-reads x: the values are never used): "if (c < C) { if (!g32) load;
+    // load; if (add) load; }" compiled to a branch and a wait around each load, six dependent round trips per row (47 us for 155 MB).
     const uint16_t* gsrc = g32 ? x : g;
     const uint16_t* asrc = add ? add : x;
-    auto request = [&](int row) {
-        nmu = mean[row]; nrs = rstd[row];
+    struct RowRegs { uint4 g[NCH], x[NCH], a[NCH]; float mu, rs; };
+    auto request = [&](RowRegs& r, int row) {
+        r.mu = mean[row]; r.rs = rstd[row];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = (lane + k * 64) * 8;
             const size_t o = (size_t)row * C + (c < C ? c : 0);
-            ng[k] = *reinterpret_cast<const uint4*>(gsrc + o);
-            nx[k] = *reinterpret_cast<const uint4*>(x + o);
-            na[k] = *reinterpret_cast<const uint4*>(asrc + o);
+            r.g[k] = *reinterpret_cast<const uint4*>(gsrc + o);
+            r.x[k] = *reinterpret_cast<const uint4*>(x + o);
+            r.a[k] = *reinterpret_cast<const uint4*>(asrc + o);
         }
     };
-    if (r0 + wave < r1) request(r0 + wave);
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const float mu = nmu, rs = nrs;
-        uint4 cg[NCH], cx[NCH], ca[NCH];
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) { cg[k] = ng[k]; cx[k] = nx[k]; ca[k] = na[k]; }
-        if (row + 4 < r1) request(row + 4);
+    // consumes r (its registers are free for the next request once this returns the unpacked values) and writes the row
+    auto process = [&](RowRegs& r, int row, int next_row) {
+        const float mu = r.mu, rs = r.rs;
         float gv[NCH][8], xh[NCH][8];
+        uint4 ca[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = (lane + k * 64) * 8;
+            ca[k] = r.a[k];
             if (c < C) {
                 float xv[8];
                 if (g32) {                                          // fp32 upstream gradient (final LayerNorm under the BN neck)
 #pragma unroll
                     for (int t = 0; t < 8; ++t) gv[k][t] = g32[(size_t)row * C + c + t];
                 } else {
-                    unpack8v(cg[k], gv[k]);
+                    unpack8v(r.g[k], gv[k]);
                 }
-                unpack8v(cx[k], xv);
+                unpack8v(r.x[k], xv);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     xh[k][t] = (xv[t] - mu) * rs;
@@ -211,6 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                 }
             }
         }
+        if (next_row < r1) request(r, next_row);
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
 #pragma unroll
@@ -229,6 +229,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                 *reinterpret_cast<uint4*>(dx + (size_t)row * C + c) = pack8v(o);
             }
         }
+    };
+    RowRegs A, B;
+    const int first = r0 + wave;
+    if (first < r1) request(A, first);
+    if (first + 4 < r1) request(B, first + 4);
+    for (int row = first; row < r1; row += 8) {
+        process(A, row, row + 8);
+        if (row + 4 < r1) process(B, row + 4, row + 12);
     }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
@@ -625,9 +633,10 @@ int launch_layernorm_fwd(hipStream_t st, const uint16_t* x, const float* gamma, 
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-// LayerNorm backward: 3 workgroups per CU in ONE round (25216 rows: 701 workgroups of 36 rows 56 us; 788 of 32 rows = 3.08 per CU 78 us,
-// 512 of 52 rows 67 us); DALI_LN_BLOCKS overrides (A/B aid)
-static int ln_block_cap() { static int v = -1; if (v < 0) { const char* e = getenv("DALI_LN_BLOCKS"); v = e ? atoi(e) : 768; } return v; }
+// LayerNorm backward: TWO workgroups per CU in one round (the kernel needs ~200 VGPRs = two 4-wave workgroups per CU; the former 768
+// "three per CU" ran as one and a half rounds): 25216 rows x 768, with the reduce behind it, 47.5 us at 768 -> 43.3 at 512, 40.4 with two
+// rows of requests ahead; three waves per SIMD spill (59.6 us), four 93.7.  DALI_LN_BLOCKS / DALI_LN_WAVES override (A/B aids).
+static int ln_block_cap() { return DALI_ENV_INT("DALI_LN_BLOCKS", 512); }
 static int rows_blocks(int rows, int per_iter, int* rpb, int cap = 2048) {
     int blocks = (rows + per_iter * 8 - 1) / (per_iter * 8);
     if (blocks > cap) blocks = cap;                    // column sums: 8 workgroups per CU (512 left too few rows in flight: 26 -> 17 us)
@@ -644,7 +653,10 @@ int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, c
     int rpb;
     const int blocks = rows_blocks(rows, 4, &rpb, ln_block_cap());
     const size_t lds = (size_t)4 * C * 2 * sizeof(float);
+    const int minw = DALI_ENV_INT("DALI_LN_WAVES", 2);                     // A/B aid: 2 (default bound), 3, 4 waves per SIMD for the C <= 1024 instantiation
     if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
+    else if (C <= 1024 && minw == 3) hipLaunchKernelGGL((layernorm_bwd_kernel<2, 3>), dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
+    else if (C <= 1024 && minw == 4) hipLaunchKernelGGL((layernorm_bwd_kernel<2, 4>), dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<LN_MAXCH>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     DALI_LAUNCH_CHECK();
