@@ -1257,7 +1257,9 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 3);
     const int a_row0 = wm * (16 * FM), b_row0 = wn * (16 * FN);
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_barrier();
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
     int st_cur = 0;
     for (int kt = 0; kt < ktiles; ++kt) {
         const uint16_t* sa = smem + st_cur * STAGE_ELEMS;
@@ -1279,7 +1281,13 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
         __builtin_amdgcn_s_barrier();
         st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
     }
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
     conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 2 && WN == 4 && NP == 8 && NSTAGE == 3) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem, wm, wn);
+    if (a.stamps) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
