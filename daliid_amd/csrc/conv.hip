@@ -178,6 +178,30 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Eight values per lane summed over the 16 lanes of a DPP row by a halving butterfly: row_mirror pairs lane l with 15 - l (the low half keeps
+// values 0-3, the high half 4-7), row_half_mirror pairs l with 7 - l inside each half, then quad permutes xor 2 and xor 1: 4 + 2 + 1 + 1 = 8 DPP
+// adds and 14 selects where eight full row sums take 32 DPP adds.  On return lanes l and l ^ 1 hold the total of value index
+// (l >= 8 ? 4 : 0) + ((l & 7) >= 4 ? 2 : 0) + ((l & 2) ? 1 : 0).  (The statistics epilogue: an ablation without its 128 DPP adds per wave ran the
+// short-K forward launches 7-12 % faster; the adds are dependent chains with DPP's extra wait states.)
+#define DALI_DPP(v, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xf, 0xf, false))
+__device__ __forceinline__ float row16_reduce8(const float (&v)[8], int lane) {
+    const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0, hi2 = (lane & 2) != 0;
+    float a[4], b[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float keep = hi8 ? v[4 + k] : v[k], send = hi8 ? v[k] : v[4 + k];
+        a[k] = keep + DALI_DPP(send, 0x140);                // row_mirror
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float keep = hi4 ? a[2 + k] : a[k], send = hi4 ? a[k] : a[2 + k];
+        b[k] = keep + DALI_DPP(send, 0x141);                // row_half_mirror
+    }
+    const float keep = hi2 ? b[1] : b[0], send = hi2 ? b[0] : b[1];
+    const float c = keep + DALI_DPP(send, 0x4e);            // quad_perm [2, 3, 0, 1]
+    return c + DALI_DPP(c, 0xb1);                           // quad_perm [1, 0, 3, 2]
+}
+
 // Shared epilogue: the per-tile BatchNorm partial statistics and the bf16 store of O (+ residual).
 // In-kernel stamps on the short-K layers showed the epilogue, not the memory system, bounding the kernel: 8 us of a 10 us
 // workgroup lifetime in VALU / LDS-crossbar work (statistics by 128 ds_bpermute shuffles, per-element predicates and
@@ -321,13 +345,11 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
             for (int j = 0; j < Cfg::FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s1[r] += v; s2[r] += v * v; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
-            if ((lane & 15) == 0) {
-                const int ml = mb + i * 16;              // first of this lane's 4 channels inside the tile
-                float4* d = reinterpret_cast<float4*>(red + (wn * TM + ml) * 2);
-                d[0] = make_float4(s1[0], s2[0], s1[1], s2[1]);
-                d[1] = make_float4(s1[2], s2[2], s1[3], s2[3]);
+            const float v8[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
+            const float tot = row16_reduce8(v8, lane);   // lanes 0-7 of the row: sums, 8-15: sums of squares; channel r = 2 * ((l & 7) >= 4) + ((l & 2) != 0)
+            if ((lane & 1) == 0) {
+                const int r = ((lane & 4) >> 1) | ((lane & 2) >> 1);
+                red[(wn * TM + mb + i * 16 + r) * 2 + ((lane >> 3) & 1)] = tot;
             }
         }
         lds_barrier();
