@@ -18,6 +18,13 @@ if MODE in ("lin", "lin_gelu", "lin_dgelu"):              # a ViT linear layer o
     pre = torch.randn(B * H * W, cout, device="cuda").to(bf16)
     run = {"lin": lambda: V.linear_fwd(xr, wr, bias), "lin_gelu": lambda: V.linear_fwd(xr, wr, bias, act=1, want_pre=True),
            "lin_dgelu": lambda: V.linear_dgrad(xr, wr, gelu_pre=pre)}[MODE]
+if MODE in ("fused", "fused_dgrad"):                  # conv3 with the fused output stage: y = relu(acc * scale + shift + residual) + mask bits (forward) /
+    xr, wr = x.reshape(-1, cin), w.reshape(cout, cin)  # a data gradient with residual + output mask
+    sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda")
+    res = torch.randn(B * H * W, cout, device="cuda").to(bf16)
+    bits = torch.randint(0, 256, (B * H * W * cout // 8,), device="cuda", dtype=torch.uint8)
+    run = {"fused": lambda: nn.conv1x1_fused(xr, wr, sc, sh, None, res, relu=True, want_bits=True),
+           "fused_dgrad": lambda: nn.conv1x1_fused(xr, wr, None, None, None, res, relu=False, out_mask=bits)}[MODE]
 for _ in range(3): run()
 nblk = 1 << 16
 stamps = torch.zeros(nblk, 12, device="cuda", dtype=torch.int64)
