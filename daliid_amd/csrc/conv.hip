@@ -344,7 +344,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
 #pragma unroll
             for (int j = 0; j < Cfg::FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s1[r] += v; s2[r] += v * v; }
+                for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s1[r] += v; s2[r] = __builtin_fmaf(v, v, s2[r]); }      // (explicit: the build has -ffp-contract=off)
             const float v8[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
             const float tot = row16_reduce8(v8, lane);   // lanes 0-7 of the row: sums, 8-15: sums of squares; channel r = 2 * ((l & 7) >= 4) + ((l & 2) != 0)
             if ((lane & 1) == 0) {
