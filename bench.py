@@ -169,9 +169,10 @@ def bench_distance(args, world, rank):
     flops = 2.0 * d * nq * ng
     achieved = flops / (k_ms * 1e-3) / 1e12
     nprod = 3 if prec == "bf16x3" else 1
+    d_traffic, d_traffic_source = committed_traffic("distance", "pairdist_bf16x3_hbm_bytes_per_launch") if nprod == 3 else (None, "no PMC pass for this precision")
     roofline = {"kernel": "pairdist_dma_kernel<%d>" % nprod, "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": d_traffic, "traffic_source": d_traffic_source,
                 "kernel_ms": round(k_ms, 4), "mfma_issue_multiplier": nprod,
                 "issue_frac": round(nprod * achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                 "note": "achieved = 2*D FLOP per pair (algorithmic) / kernel time; bf16x3 issues 3 bf16 MFMA products per algorithmic "
@@ -222,7 +223,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def committed_traffic(which):
+def committed_traffic(which, key="gemm_kernels_hbm_bytes_per_step"):
     """HBM bytes per step of the GEMM kernels from the committed PMC pass (profiles/*_pmc_traffic.json: rocprofv3 --pmc in
     its own run, corrected as MI355X_MICROARCH.md prescribes).  -> (bytes or None, provenance string).  The number is NOT
     measured in this run; it is reported only while the kernel sources still hash to what the profile was taken on."""
@@ -231,7 +232,7 @@ def committed_traffic(which):
         try:
             with open(path) as f:
                 j = json.load(f)
-            val = j["gemm_kernels_hbm_bytes_per_step"]
+            val = j[key]
         except (OSError, KeyError, ValueError):
             continue
         want, have = j.get("kernel_source_hash"), kernel_source_hash()

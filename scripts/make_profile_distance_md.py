@@ -30,5 +30,9 @@ if os.path.exists(src + "/pmc_mfma.md"):
     out.append("\nMFMA utilisation (`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE` in its own run, "
                "`scripts/pmc_mfma.py`; per launch, 8 launches in the process; bf16x3 issues three MFMA products per algorithmic one):\n")
     out.append(open(src + "/pmc_mfma.md").read())
+if os.path.exists(src + "/pmc_traffic.json"):
+    shutil.copy(src + "/pmc_traffic.json", "profiles/%s_distance_pmc_traffic.json" % RND)
+    out.append("\nHBM traffic per launch (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run; `scripts/pmc_traffic_distance.py`; algorithmic: 4.0 GB of "
+               "distances written + 0.9 GB of operand images read once):\n\n```\n%s\n```\n" % open(src + "/pmc_traffic.json").read().strip())
 open("profiles/%s_distance_kernel_stats.md" % RND, "w").write("\n".join(out) + "\n")
 print("wrote profiles/%s_distance_kernel_stats.md" % RND)

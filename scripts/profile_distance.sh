@@ -15,3 +15,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_
 python scripts/pmc_mfma.py $O/mfma 8 $O/pmc_mfma.md > /dev/null
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/clock -- python bench.py --workload distance --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/clock.err || exit 5
 python scripts/effective_clock.py $O/clock pairdist_dma > $O/clock.txt
+# HBM traffic of the distance / ranking kernels: FETCH_SIZE and WRITE_SIZE, each in a pass of its own
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python bench.py --workload distance --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/fetch.err || exit 7
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py --workload distance --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/write.err || exit 8
+python scripts/pmc_traffic_distance.py $O/fetch $O/write $O/pmc_traffic.json > /dev/null
