@@ -290,9 +290,8 @@ extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, co
     float* dot = reinterpret_cast<float*>(p);
     int rc;
     if (fused_cs) wa.colsum = cs_partial;
-    if ((rc = launch_igemm_wgrad(st, wa, gram, 0))) return rc;
-    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, m2, (size_t)w, cs_rows, 0))) return rc; }
-    else if ((rc = launch_colsum(st, a, P, w, m2, cs_partial, scratch))) return rc;
+    if ((rc = launch_igemm_wgrad(st, wa, gram, 0, fused_cs ? m2 : nullptr, cs_rows))) return rc;
+    if (!fused_cs && (rc = launch_colsum(st, a, P, w, m2, cs_partial, scratch))) return rc;
     if ((rc = launch_weight_transpose(st, W, C, 1, w, wt))) return rc;
     return launch_bnlin_stats(st, wt, gram, m2, C, w, (double)P, gamma, beta, running_mean, running_var, momentum, eps, ut, dot, scale, shift, mean, invstd);
 }
@@ -321,8 +320,7 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     float* qk = reinterpret_cast<float*>(p);
     int rc;
     if (fused_cs) wa.colsum = cs_partial;
-    if ((rc = launch_igemm_wgrad(st, wa, dW, 0))) return rc;                       // G0 -> dW
-    if (fused_cs) { if ((rc = launch_splitk_reduce(st, cs_partial, sdz, (size_t)C, cs_rows, 0))) return rc; }
-    else if ((rc = launch_colsum(st, dz, P, C, sdz, cs_partial, scratch))) return rc;
+    if ((rc = launch_igemm_wgrad(st, wa, dW, 0, fused_cs ? sdz : nullptr, cs_rows))) return rc;                       // G0 -> dW
+    if (!fused_cs && (rc = launch_colsum(st, dz, P, C, sdz, cs_partial, scratch))) return rc;
     return launch_bnlin_bwd(st, W, ut, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
 }

@@ -2580,7 +2580,7 @@ __device__ __forceinline__ void wgrad_p_produce(const WGradArgs& a, uint16_t* sm
     }
 }
 
-template <int WM, int WN, int FM, int FN, int NP, int NSTAGE>
+template <int WM, int WN, int FM, int FN, int NP, int NSTAGE, bool COLSUM = false>
 __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGradArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NC = WM * WN;
     constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128, STAGE = NIMG * IMG;
@@ -2659,6 +2659,42 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGra
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
     };
+    // COLSUM (bias gradients of the linear layers): column sums of dY over this split's pixels, as in igemm_wgrad_wgs_kernel: one more MFMA per A fragment
+    // against a column-select operand (fragment i' of a wave's share lands in result column 4 i'), the n tiles of an (m tile, split) taking the k-steps
+    // in turn.  The WN waves of a consumer row hold the same FM A fragments: each sums FM / WN of them (all on the wn-0 wave, 8 extra MFMAs in its turn
+    // steps while the other three waited at the barrier: 4.76 ms for the ViT's 48 weight gradients against 4.67 shared).
+    constexpr int CSF = FM / WN;
+    static_assert(!COLSUM || (FM % WN == 0 && CSF <= 4), "column sums: the fragments must divide over the waves of a row");
+    const bool do_cs = COLSUM;
+    int cs_turn = tn;
+    f32x4_t cs = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int cs_col = (lane & 15) >> 2;
+    auto colsum_step = [&](const bf16x8_t (&fa)[FM]) {
+        if constexpr (COLSUM) if (do_cs) {
+            if (cs_turn == 0) {
+                typedef unsigned sel_vec_t __attribute__((ext_vector_type(4)));
+                int opaque;                                        // built per use (hoisted they would cost registers across the pipelined loop)
+                asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+                // this wave's share, one branch per wave index with CONSTANT fragment indices inside (a selected fa[q * CSF + i] made fa a
+                // dynamically indexed array: 272 bytes of scratch, the kernel four times slower)
+                auto share = [&](auto qc) {
+                    constexpr int Q = decltype(qc)::value;
+#pragma unroll
+                    for (int i = 0; i < CSF; ++i) {
+                        const unsigned w = (cs_col + opaque == i) ? 0x3F803F80u : 0u;    // bf16 (1, 1) or (0, 0)
+                        cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[Q * CSF + i], __builtin_bit_cast(bf16x8_t, sel_vec_t{w, w, w, w}), cs, 0, 0, 0);
+                    }
+                };
+                static_assert(WN == 4, "column sums: four waves per consumer row");
+                if (wn == 0) share(std::integral_constant<int, 0>{});
+                else if (wn == 1) share(std::integral_constant<int, 1>{});
+                else if (wn == 2) share(std::integral_constant<int, 2>{});
+                else share(std::integral_constant<int, 3>{});
+                cs_turn = tiles_n;
+            }
+            --cs_turn;
+        }
+    };
     if (ksteps > 0) {
         bf16x8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
         __builtin_amdgcn_s_barrier();                              // P0: k-steps 0 and 1 have landed
@@ -2670,24 +2706,34 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGra
             load_frags(fa1, fb1, st1);
             multiply(fa0, fb0);
             interleave();
+            colsum_step(fa0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of k-step t+1 are complete: its stage may be refilled after E_t
             __builtin_amdgcn_s_barrier();                          // E_t
             const int st2 = (t + 2 < ksteps) ? (st1 + 1 == NSTAGE ? 0 : st1 + 1) : st1;
             load_frags(fa0, fb0, st2);
             multiply(fa1, fb1);
             interleave();
+            colsum_step(fa1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // E_{t+1}
             st1 = st2 + 1 == NSTAGE ? 0 : st2 + 1;
         }
         if (t < ksteps) {                                          // odd count: the last k-step is in set 0
             multiply(fa0, fb0);
+            colsum_step(fa0);
             __builtin_amdgcn_s_barrier();                          // E_{ksteps-1}
         }
     }
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
     float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
     store_slab_tiles<FM, FN>(slab, acc, m0 + wm * 16 * FM, n0 + wn * 16 * FN, a.Cm, a.Ntot, lane);
+    if constexpr (COLSUM) if (do_cs && (lane & 3) == 0 && cs_col < CSF) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int m = m0 + wm * 16 * FM + (wn * CSF + cs_col) * 16 + (lane >> 4) * 4 + rr;
+            if (m < a.Cm) a.colsum[((size_t)ks * tiles_n + tn) * a.Cm + m] = cs[rr];
+        }
+    }
     if (a.stamps) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2706,12 +2752,17 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGra
 //     computation reads the workgroup size from the DISPATCH PACKET (host memory) at the start of every wave.  The path never ran at the plan's
 //     shapes and cost them 30 us per launch whatever the wave count (3.5-13 us without it: 34 MB, resp. 76 MB, of slabs).  The odd sizes
 //     have their own kernel now; check new kernels for ".amdhsa_user_sgpr_dispatch_ptr 1".
+// A second, small job (the column sums that rode on the same weight-gradient GEMM: bias gradients, the Gram scheme's sums) can share the launch:
+// the workgroups behind the first job's nb1 take it (a launch of its own cost 5-8 us, 48 times per ViT step).
+struct ReduceJob2 { const float* partial; float* out; size_t elems; int splits; unsigned nb1; };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                  size_t elems, int splits, int accumulate) {      // elems % 4 == 0
+                                                                  size_t elems, int splits, int accumulate, ReduceJob2 j2) {      // elems % 4 == 0
     __shared__ float4 red[WAVES > 1 ? WAVES * 64 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const size_t i4 = ((size_t)blockIdx.x * 64 + lane) * 4;
+    unsigned blk = blockIdx.x;
+    if (blk >= j2.nb1) { blk -= j2.nb1; partial = j2.partial; out = j2.out; elems = j2.elems; splits = j2.splits; accumulate = 0; }     // (wave-uniform)
+    const size_t i4 = ((size_t)blk * 64 + lane) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool in = i4 < elems;
     if (in) {
@@ -3093,7 +3144,9 @@ static int wgrad_spec_env() { return DALI_ENV_INT("DALI_WGRAD_SPEC", -1); }
 static bool wgrad_spec(int Cm, int Ntot) {
     const int ov = wgrad_spec_env();
     if (ov >= 0) return ov != 0;
-    return ((Cm + 127) / 128) * ((Ntot + 255) / 256) <= DALI_ENV_INT("DALI_WGRAD_SPEC_TILES", 40);
+    // (40 until the pipelined kernel carried the column sums: with them it wins at the ViT's 54 / 72 tiles too -- 48 weight gradients 5.46 -> 4.67 ms --
+    //  and at layer4's downsample, 64 tiles: 162 -> 125 us)
+    return ((Cm + 127) / 128) * ((Ntot + 255) / 256) <= DALI_ENV_INT("DALI_WGRAD_SPEC_TILES", 100);
 }
 // DALI_WGRAD_P (A/B aid): 0 = the round-2 kernels, 1 (default) = igemm_wgrad_p_kernel with 4 consumers of 128 x 64 + 4 producers, 2 = with 8 consumers of
 // 64 x 64 + 4 producers, 3 = 8 consumers + 8 producers
@@ -3141,7 +3194,7 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
     *ws_bytes = (size_t)sp * Cm * Ntot * sizeof(float);
 }
 
-int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate) {
+int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate, float* colsum_out, int colsum_rows) {
     WGradArgs args = a;
     args.stamps = g_conv_stamps;
     args.g.lw = ilog2_exact(a.g.Wout);
@@ -3197,18 +3250,25 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
         });
         const dim3 grid2(((tm2 * tn2 * a.splits + 7) / 8) * 8);
         const int pmode = wgrad_p_mode();
-        if (pmode && !a.colsum && wgrad_spec(a.Cm, a.Ntot)) {   // (where the specialised kernel ran: few output tiles, one workgroup per CU)
+        const bool p_cs = DALI_ENV_INT("DALI_WGRAD_P_CS", 1) != 0;          // A/B aid: 0 = column sums on the round-2 kernels
+        if (pmode && (!a.colsum || p_cs) && wgrad_spec(a.Cm, a.Ntot)) {   // (where the specialised kernel ran: few output tiles, one workgroup per CU)
             constexpr int lds_p = 6 * 3 * 32 * 128 * 2;   // 6 stages x 3 images x 8 KiB
             DALI_ONCE_PER_DEVICE({
                 DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
                 DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
                 DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
+                DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
+                DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
             });
             // (measured, interleaved: plain [P][C] operands 92 us with 4 consumers of 128 x 64 + 4 producers against 94 with 8 + 8 and 105 before;
             //  strided / gathered operands 83 us with 4 producers of 6 pieces, 75 with 8 of 3)
             const GatherGeom& gg = a.g;
             const bool flat = gg.R == 1 && gg.S == 1 && gg.stride == 1 && gg.pad == 0 && gg.pix_pitch == gg.Ck && gg.row_pitch == gg.Win * gg.Ck &&
                               gg.img_pitch == (long long)gg.Hin * gg.Win * gg.Ck && gg.Hin == gg.Hout && gg.Win == gg.Wout;
+            if (a.colsum) {                                     // bias gradients of the linear layers / the Gram scheme's column sums ride on the GEMM
+                if (pmode == 3 || !flat) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6, true>), grid2, dim3(1024), lds_p, st, args, tm2, tn2);
+                else hipLaunchKernelGGL((igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6, true>), grid2, dim3(512), lds_p, st, args, tm2, tn2);
+            } else
             if (pmode == 3 || (pmode == 1 && !flat)) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6>), grid2, dim3(1024), lds_p, st, args, tm2, tn2);
             else if (pmode == 2) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 4, 6>), grid2, dim3(768), lds_p, st, args, tm2, tn2);
             else hipLaunchKernelGGL((igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6>), grid2, dim3(512), lds_p, st, args, tm2, tn2);
@@ -3226,7 +3286,9 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
     }
     DALI_LAUNCH_CHECK();
     if (!out) return DALI_OK;                       // the caller reduces the slabs itself
-    return launch_splitk_reduce(st, a.partial, out, (size_t)a.Cm * a.Ntot, a.splits, accumulate);
+    // the column sums that rode on the GEMM (a.colsum, colsum_rows partial rows of Cm) are reduced in the same launch
+    return launch_splitk_reduce2(st, a.partial, out, (size_t)a.Cm * a.Ntot, a.splits, accumulate, (a.colsum && colsum_out) ? a.colsum : nullptr, colsum_out,
+                                 (size_t)a.Cm, colsum_rows);
 }
 
 // rows of the column-sum partial slab [rows][Cm] a weight-gradient launch with WGradArgs::colsum leaves: one per split from the
@@ -3240,11 +3302,14 @@ bool wgrad_colsum_supported(int Cm, int Ntot, int taps, int P) {
 }
 
 int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate) {
+    return launch_splitk_reduce2(st, partial, out, elems, splits, accumulate, nullptr, nullptr, 0, 0);
+}
+// partial2 / out2 (nullable): a second job in the same launch (ReduceJob2); falls back to a launch of its own when either job has an odd element count
+int launch_splitk_reduce2(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate,
+                          const float* partial2, float* out2, size_t elems2, int splits2) {
     if (DALI_ENV_INT("DALI_DEBUG_SKIP_REDUCE", 0)) return DALI_OK;      // timing aid only (wrong results): what the reduce launches cost a step
     const size_t chunks = (elems + 3) / 4;
     const unsigned rblocks = (unsigned)((chunks + 63) / 64);
-    // waves per chunk column: enough for ~1024 waves in the launch, at most 16, and at least 4 slabs per wave.  A function of (elems, splits)
-    // only, so the summation order of a given weight gradient never changes from step to step.
     // waves per chunk column: 16 from 32 slabs on, else 4.  (An adaptive rule -- about 1024 waves per launch, at least 4 slabs per wave --
     // measured the same standalone and 0.1 - 0.2 ms per train step SLOWER in the step, DALI_REDUCE_WAVES=-2; what made the reduce slow
     // was the serialised loads described in the kernel, not the wave count.)  A function of (elems, splits) only, so the summation order
@@ -3253,17 +3318,25 @@ int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_
     const int ov = DALI_ENV_INT("DALI_REDUCE_WAVES", 0);               // A/B aid: force 1 / 2 / 4 / 8 / 16; -2 = the adaptive rule
     if (ov == -2) { W = 1; while (W < 16 && (size_t)rblocks * W < 1024 && splits >= 8 * W) W *= 2; }
     else if (ov > 0) W = ov;
+    const bool second = partial2 && out2 && elems2 > 0;
+    if (second && ((elems & 3) || (elems2 & 3) || !DALI_ENV_INT("DALI_REDUCE_FUSE2", 1))) {        // own launches (DALI_REDUCE_FUSE2=0: A/B aid)
+        if (int rc = launch_splitk_reduce2(st, partial, out, elems, splits, accumulate, nullptr, nullptr, 0, 0)) return rc;
+        return launch_splitk_reduce2(st, partial2, out2, elems2, splits2, 0, nullptr, nullptr, 0, 0);
+    }
     if (elems & 3) {
         hipLaunchKernelGGL(splitk_reduce_odd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, partial, out, elems, splits, accumulate, W);
         DALI_LAUNCH_CHECK();
         return DALI_OK;
     }
+    ReduceJob2 j2{nullptr, nullptr, 0, 0, 0xffffffffu};
+    unsigned grid = rblocks;
+    if (second) { j2 = ReduceJob2{partial2, out2, elems2, splits2, rblocks}; grid += (unsigned)((elems2 / 4 + 63) / 64); }
     switch (W) {
-        case 1: hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(rblocks), dim3(64), 0, st, partial, out, elems, splits, accumulate); break;
-        case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(rblocks), dim3(128), 0, st, partial, out, elems, splits, accumulate); break;
-        case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, st, partial, out, elems, splits, accumulate); break;
-        case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(rblocks), dim3(512), 0, st, partial, out, elems, splits, accumulate); break;
-        default: hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(rblocks), dim3(1024), 0, st, partial, out, elems, splits, accumulate); break;
+        case 1: hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(grid), dim3(64), 0, st, partial, out, elems, splits, accumulate, j2); break;
+        case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(grid), dim3(128), 0, st, partial, out, elems, splits, accumulate, j2); break;
+        case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(grid), dim3(256), 0, st, partial, out, elems, splits, accumulate, j2); break;
+        case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(grid), dim3(512), 0, st, partial, out, elems, splits, accumulate, j2); break;
+        default: hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(grid), dim3(1024), 0, st, partial, out, elems, splits, accumulate, j2); break;
     }
     DALI_LAUNCH_CHECK();
     return DALI_OK;
@@ -3431,9 +3504,7 @@ int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, f
     const bool ride = fuse && dbias && cs_partial && wgrad_colsum_supported(N, K, 1, rows);
     if (bias_done) *bias_done = ride;
     if (ride) a.colsum = cs_partial;
-    int rc = launch_igemm_wgrad(st, a, dw, 0);
-    if (rc || !ride) return rc;
-    return launch_splitk_reduce(st, cs_partial, dbias, (size_t)N, wgrad_colsum_rows(N, K, 1, rows, a.splits), 0);
+    return launch_igemm_wgrad(st, a, dw, 0, ride ? dbias : nullptr, ride ? wgrad_colsum_rows(N, K, 1, rows, a.splits) : 0);
 }
 size_t linear_wgrad_colsum_floats(int rows, int K, int N) {
     int sp, pps; size_t wsb;

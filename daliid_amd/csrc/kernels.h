@@ -83,7 +83,10 @@ int igemm_conv_stat_tiles(int Cm, int P, int K);
 // halo_w = output width of a 3x3 / stride 1 / pad 1 convolution whose H*W is a power of two (0 otherwise): enables the halo kernel
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps = 1, int halo_w = 0);
 // out == nullptr: leave the split-K slabs in a.partial ([splits][Cm][Ntot]) for the caller to reduce
-int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate);
+// colsum_out (nullable): where the column sums that rode on the GEMM (a.colsum, colsum_rows partial rows) are reduced to, in the slab reduce's launch
+int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate, float* colsum_out = nullptr, int colsum_rows = 0);
+int launch_splitk_reduce2(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate,
+                          const float* partial2, float* out2, size_t elems2, int splits2);
 bool wgrad_colsum_supported(int Cm, int Ntot, int taps, int P);
 // out[e] (+)= sum_k partial[k][e], fixed order
 int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate);

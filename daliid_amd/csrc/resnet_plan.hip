@@ -556,9 +556,8 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                 wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
                 const bool fused_cs = wgrad_colsum_supported(wa.Cm, wa.Ntot, 1, wa.P);      // m2 = colsum(a2) rides on the Gram GEMM
                 if (fused_cs) wa.colsum = net->cs_partial;
-                if ((rc = launch_igemm_wgrad(st, wa, b.gram, 0))) return rc;
-                if (fused_cs) { if ((rc = launch_splitk_reduce(st, net->cs_partial, b.m2, (size_t)b.width, wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits), 0))) return rc; }
-                else if ((rc = launch_colsum(st, b.a2, Pout, b.width, b.m2, net->cs_partial, net->red_scratch))) return rc;
+                if ((rc = launch_igemm_wgrad(st, wa, b.gram, 0, fused_cs ? b.m2 : nullptr, fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;
+                if (!fused_cs && (rc = launch_colsum(st, b.a2, Pout, b.width, b.m2, net->cs_partial, net->red_scratch))) return rc;
                 if ((rc = launch_bnlin_stats(st, b.c3.wt_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
                                              net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.ut, b.dot, b.b3.scale, b.b3.shift, b.b3.mean,
                                              b.b3.invstd))) return rc;
@@ -609,9 +608,9 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         const bool fused_cs = wgrad_colsum_supported(wa.Cm, wa.Ntot, 1, wa.P);              // s = colsum(dz) rides on the weight-gradient GEMM
         if (fused_cs) wa.colsum = net->cs_partial;
         if (side_mode() == 2 && (rc = wgrad_join(net, st))) return rc;
-        if ((rc = launch_igemm_wgrad(st, wa, net->G + b.c3.w_off, 0))) return rc;           // G0 = dz^T a2 into the gradient slot; finished in place below
-        if (fused_cs) { if ((rc = launch_splitk_reduce(st, net->cs_partial, b.sdz, (size_t)b.cout, wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits), 0))) return rc; }
-        else if ((rc = launch_colsum(st, dz, Pout, b.cout, b.sdz, net->cs_partial, net->red_scratch))) return rc;
+        if ((rc = launch_igemm_wgrad(st, wa, net->G + b.c3.w_off, 0, fused_cs ? b.sdz : nullptr,
+                                     fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;           // G0 = dz^T a2 into the gradient slot; finished in place below
+        if (!fused_cs && (rc = launch_colsum(st, dz, Pout, b.cout, b.sdz, net->cs_partial, net->red_scratch))) return rc;
         if ((rc = launch_bnlin_bwd(st, b.c3.w_bf16, b.ut, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
                                    b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.wd1, b.wd2, b.bvec, b.qk))) return rc;
         d_a2 = next_gbuf(net, dz);
