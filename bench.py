@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the DaliID Person-ReID hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload train|vit|distance]
+    python bench.py --gpus N --steps K --warmup W [--workload train|vit|distance|epoch]
 
 Prints ONE JSON line (rank 0).  Workloads (BASELINE.json):
   * train    (configs[1]): ResNet-50 ReID bf16, PK batch 16x16=256 per GPU, center + proxy heads, Adam, EMA;
@@ -9,7 +9,9 @@ Prints ONE JSON line (rank 0).  Workloads (BASELINE.json):
                The default run also carries the other half of BASELINE.json's metric as a ``"distance"`` sub-record
                (configs[4], below) unless --no-distance is given.
   * distance (configs[4]): 10k x 100k x 2048 cosine distmat (+ CMC/mAP timed separately); metric Gpairs/sec.
-  * vit      (configs[3]): TransReID ViT-B/16 train step, batch 128 per GPU.
+  * vit      (configs[3]): TransReID ViT-B/16 train step, batch 128 per GPU (also a ``"vit"`` sub-record of the default run).
+  * epoch    one Market-1501-shaped epoch of trainer.train (12,936-image inference + 751-id targets + 46 PK steps of 384), the
+               only thing the reference's logs time; also an ``"epoch"`` sub-record of the default run.
 Inputs are synthetic and resident in HBM before the timed region.
 
 ``--gpus N`` with N > 1: when no launcher has set WORLD_SIZE, this process starts N ranks itself
@@ -434,6 +436,86 @@ def bench_train(args, world, rank):
             "roofline": roofline, "cpu_baseline": cpu, "comm": comm}
 
 
+def bench_epoch(args, world, rank):
+    """One Market-1501-shaped epoch of ``trainer.train`` (train_encodersKIT.py:104-156,176-235) on device-resident synthetic
+    images: eval-mode inference of the 12,936 train images at batch 500 (getFeatures.py:47-71) -> class centers + 5
+    farthest-point proxies for 751 identities -> 46 PK steps of 16 identities x 12 images x (clean, distorted) = 384 images
+    (mainKIT.py:326-327,340 defaults, AT pairing).  The product's own entry points run (extractFeatures,
+    build_centers_and_proxies, samplePKBatches, trainer.train); only decode / augmentation are replaced by a gather from an
+    image pool in HBM (no dataloader in the timed region).  The reference's log lines for the same epoch
+    (log_AT_training_Market.txt:14,19 and :7269: 9.49 s inference, 70.43 s per epoch, 3 unnamed GPUs, JPEG decode included)
+    are context, not a target."""
+    import numpy as np
+    from daliid_amd import Encoders, getFeatures, train_encodersKIT as T
+    device = torch.device("cuda", torch.cuda.current_device())
+    N, NID, P, K, H, W = 12936, 751, 16, 12, 256, 128
+    gen = torch.Generator(device=device).manual_seed(12 + rank)
+    pool = torch.empty(N, 3, H, W, device=device)
+    for b in range(0, N, 1024):
+        pool[b:b + 1024] = torch.randn(min(1024, N - b), 3, H, W, device=device, generator=gen)
+    labels = (np.arange(N) % NID).astype(np.int32)
+    records = np.array([["pool://%d" % i, str(labels[i]), str(i % 6), "person"] for i in range(N)])
+
+    def loader(paths, img_height, img_width, turb=None):
+        idx = torch.tensor([int(p[7:]) for p in paths], device=device)
+        if turb is not None:                                  # the distorted partner: another image of the pool
+            idx = (idx + 97 * int(turb[1])) % N
+        return pool[idx]
+    getFeatures.set_image_loader(loader); T.set_train_loader(loader)
+    try:
+        online = Encoders._DataParallelShim(Encoders.ResNet50ReID(device=device, seed=12))
+        momentum = Encoders._DataParallelShim(Encoders.ResNet50ReID(device=device, seed=12))
+        pg = None
+        if world > 1:
+            import torch.distributed as dist
+            pg = dist.group.WORLD
+        drv = torch.optim.Adam(online.parameters(), lr=3.5e-4, weight_decay=5e-4)
+        tr = T.trainer("Synthetic", records, "resnet50", {}, H, W, "pool", False, 1, drv, P, K, 0.05, 0.999, 0.4, 250, online, momentum,
+                       [device.index], "bench", process_group=pg)
+        import contextlib, io
+        quiet = contextlib.redirect_stdout(io.StringIO())
+        with quiet:
+            tr.train(records, labels, 1, 10)                  # warm-up epoch (plan construction for batch 500 / 436 / 384, allocator)
+        barrier_sync(world)
+        # (1) inference alone
+        t0 = time.perf_counter()
+        with quiet:
+            fvs = getFeatures.extractFeatures(records, H, W, online, 500, gpu_index=device.index, keep_on_device=True)
+        torch.cuda.synchronize()
+        t_inf = time.perf_counter() - t0
+        # (2) centers + proxies alone
+        np.random.seed(12)
+        T.build_centers_and_proxies(fvs, labels, 5); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        T.build_centers_and_proxies(fvs, labels, 5)
+        torch.cuda.synchronize()
+        t_tgt = time.perf_counter() - t0
+        del fvs
+        # (3) the whole epoch through trainer.train
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        with quiet:
+            tr.train(records, labels, 1, 10)
+        barrier_sync(world)
+        t_epoch = max_over_ranks(time.perf_counter() - t0, world)
+        st = tr.last_epoch_stats
+    finally:
+        getFeatures.set_image_loader(None); T.set_train_loader(None)
+    steps = int(st["steps"])
+    t_loop = t_epoch - t_inf - t_tgt
+    return {"metric": "epoch seconds (trainer.train: inference + targets + PK loop)", "value": round(t_epoch, 3), "unit": "s",
+            "higher_is_better": False,
+            "config": {"workload": "Market-1501-shaped synthetic epoch, ResNet-50 bf16 256x128: %d images eval-mode at batch 500, %d ids, "
+                                   "%d PK steps of %d images (P=%d, K=%d, clean + distorted); device-resident image pool, per GPU"
+                                   % (N, NID, steps, 2 * P * K, P, K)},
+            "inference_images_per_s": round(N / t_inf, 1), "inference_s": round(t_inf, 3),
+            "targets_ms": round(t_tgt * 1e3, 2),
+            "pk_steps": steps, "pk_loop_s": round(t_loop, 3), "pk_images_per_s": round(world * steps * 2 * P * K / max(t_loop, 1e-9), 1),
+            "mean_loss": float(st["loss"]),
+            "reference_context": "log_AT_training_Market.txt:14,19 / :7269: 9.49 s inference, 70.43 s per epoch on 3 unnamed GPUs, JPEG decode and "
+                                 "PIL transforms included (here: device-resident pool) -- context, not a target"}
+
+
 def allreduce_probe(tr, world, steps):
     """The gradient all-reduce of one step alone (all stage buckets back to back on the reducer's stream, nothing to overlap
     with): ms per step and bus bandwidth, so that the scaling curve can be read against the collective's own cost."""
@@ -498,11 +580,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=["train", "vit", "distance"])
+    ap.add_argument("--workload", default="train", choices=["train", "vit", "distance", "epoch"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 256 for train, 128 for vit)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-distance", action="store_true", help="train workload: skip the configs[4] distance sub-record")
+    ap.add_argument("--no-vit", action="store_true", help="train workload: skip the configs[3] ViT-B/16 sub-record")
+    ap.add_argument("--no-epoch", action="store_true", help="train workload: skip the Market-shaped epoch sub-record")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -517,6 +601,8 @@ def main():
         sys.exit(0 if os.environ.get("DALIID_BENCH_CHILD") else 3)      # the self-launching parent turns the error line into status 3
     if args.workload == "distance":
         res = bench_distance(args, world, rank)
+    elif args.workload == "epoch":
+        res = bench_epoch(args, world, rank)
     else:
         res = bench_train(args, world, rank)
         if args.workload == "train" and not args.no_distance:
@@ -525,7 +611,19 @@ def main():
             d = bench_distance(args, world, rank)
             d.pop("metric")
             res["distance"] = d
-    res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+        if args.workload == "train" and not args.no_vit:
+            # configs[3] in the driver's line as well: 5 warm-up + 20 timed ViT-B/16 steps (~0.6 s)
+            torch.cuda.empty_cache()
+            va = argparse.Namespace(**vars(args))
+            va.workload, va.batch, va.steps, va.warmup, va.no_cpu_baseline = "vit", 0, 20, 5, True
+            v = bench_train(va, world, rank)
+            v.pop("metric"); v["steps"], v["warmup"] = va.steps, va.warmup
+            res["vit"] = v
+        if args.workload == "train" and not args.no_epoch:
+            torch.cuda.empty_cache()
+            e = bench_epoch(args, world, rank)
+            res["epoch"] = e
+    res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": args.workload != "epoch",
                 "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
     if world > 1:
         res["world_size_seen"] = ranks_seen(world)          # from an all-reduce of ones on the NCCL (= RCCL) group

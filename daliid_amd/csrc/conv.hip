@@ -3344,10 +3344,10 @@ int launch_splitk_reduce2(hipStream_t st, const float* partial, float* out, size
 
 }  // namespace dali
 
-// Diagnostic (not in include/daliid.h): device buffer of 4 x uint64 per block that the LDS-DMA conv kernel fills with
+// Diagnostic (include/daliid_debug.h): device buffer of 4 x uint64 per block that the LDS-DMA conv kernel fills with
 // s_memrealtime stamps (100 MHz); null switches it off.  scripts/conv_block_timeline.py reads it.
 extern "C" int dali_debug_set_conv_stamps(void* dev_ptr) { g_conv_stamps = static_cast<unsigned long long*>(dev_ptr); return DALI_OK; }
-// Diagnostics for scripts/bench_reduce.py (not in include/daliid.h): the split count wgrad_plan picks, and the reduce alone.
+// Diagnostics for scripts/bench_reduce.py (include/daliid_debug.h): the split count wgrad_plan picks, and the reduce alone.
 extern "C" int dali_debug_wgrad_splits(int Cm, int Ntot, int P, int taps, int halo_w) {
     int sp = 0, pps = 0; size_t wsb = 0;
     wgrad_plan(Cm, Ntot, P, 512, &sp, &pps, &wsb, taps, halo_w);

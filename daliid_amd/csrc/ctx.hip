@@ -67,7 +67,7 @@ int rf_counter_base(unsigned int** out) {
 
 extern "C" int dali_version(void) { return 100; }
 
-// Diagnostic (not in include/daliid.h): the DALI_* A/B switches are re-read from the environment at their next use.
+// Diagnostic (include/daliid_debug.h): the DALI_* A/B switches are re-read from the environment at their next use.
 extern "C" int dali_debug_reload_env(void) { dali::env_reload(); return DALI_OK; }
 
 extern "C" const char* dali_last_error(void) { return dali::g_err; }

@@ -8,8 +8,8 @@ from conftest import ROOT
 from daliid_amd import _lib
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "daliid.h")).read()
+def _declared(header="daliid.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dali_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,6 +22,21 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(L, name), "libdaliid_hip.so does not export %s" % name
     assert sorted(_lib.exported_symbols()) == declared, "ctypes table and header disagree"
     assert L.dali_version() >= 100
+
+
+def test_library_exports_exactly_what_the_headers_declare():
+    """`nm -D` of the shared library against the two headers: the drop-in surface (daliid.h) plus the diagnostic entry points
+    (daliid_debug.h, bound by scripts/ only).  An export that no header names, or a declaration without a definition, fails here."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TW" and ln.split()[-1].startswith("dali_")})
+    surface, debug = _declared(), _declared("daliid_debug.h")
+    assert debug and all(n.startswith("dali_debug_") for n in debug)
+    assert not set(surface) & set(debug)
+    assert exported == sorted(surface + debug), (sorted(set(exported) - set(surface + debug)), sorted(set(surface + debug) - set(exported)))
+    assert not [n for n in _lib.exported_symbols() if n.startswith("dali_debug_")], "the product binds a diagnostic entry point"
 
 
 def test_no_cpu_fallback():

@@ -5,6 +5,7 @@ import torch
 
 from oracle import evalrank as E
 from oracle import losses as OL
+from oracle.resnet50_bf16 import forward_matched
 from oracle.resnet50_reid import ResNet50ReID as OracleNet
 from oracle.trainstep import l2norm_train
 
@@ -55,8 +56,14 @@ def test_first_step_losses_match_oracle_and_training_reduces_loss(env):
     fn = l2norm_train(ref(imgs.cpu()))
     c_ref = OL.center_loss(fn, blabels, dist, heads.centers.cpu(), heads.clabels.cpu().numpy(), 1, 250, 0.05)[0].item()
     p_ref = OL.proxy_loss(fn, blabels, dist, heads.proxies.cpu(), heads.plabels.cpu().numpy(), 1, 250, 0.05).item()
-    print("first step: center %.4f (oracle %.4f)  proxy %.4f (oracle %.4f)" % (c_hip, c_ref, p_hip, p_ref))
-    assert abs(c_hip - c_ref) < 0.05 * abs(c_ref) + 0.02 and abs(p_hip - p_ref) < 0.05 * abs(p_ref) + 0.02
+    # the same step through the rounding-matched twin (fp32 arithmetic, bf16 round trips where the kernels store bf16): the bound on
+    # HIP-vs-fp32 is the twin's own distance from fp32 (x 1.5) plus a fixed 0.5 % -- not a percentage picked to pass
+    fn_t = l2norm_train(forward_matched(ref, imgs.cpu()))
+    c_twin = OL.center_loss(fn_t, blabels, dist, heads.centers.cpu(), heads.clabels.cpu().numpy(), 1, 250, 0.05)[0].item()
+    p_twin = OL.proxy_loss(fn_t, blabels, dist, heads.proxies.cpu(), heads.plabels.cpu().numpy(), 1, 250, 0.05).item()
+    print("first step: center %.4f (oracle %.4f, twin %.4f)  proxy %.4f (oracle %.4f, twin %.4f)" % (c_hip, c_ref, c_twin, p_hip, p_ref, p_twin))
+    assert abs(c_hip - c_ref) < 1.5 * abs(c_twin - c_ref) + 5e-3 * abs(c_ref), (c_hip, c_ref, c_twin)
+    assert abs(p_hip - p_ref) < 1.5 * abs(p_twin - p_ref) + 5e-3 * abs(p_ref), (p_hip, p_ref, p_twin)
     # Adam moved the online weights by ~lr, the momentum model by (1-beta) of that
     d_on = (online.module.flat_params - params_before).abs().max().item()
     assert 1e-4 < d_on < 1e-3
