@@ -39,6 +39,33 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict_
         if (norms) norms[row] = nrm;
         if (sq) sq[row] = normalize ? (ss / (den * den)) : ss;
     }
+    if (vec && Kp == d && (reinterpret_cast<uintptr_t>(yout) & 15) == 0) {
+        // second sweep, whole float4 chunks (d % 4 == 0, no column padding): 16-byte loads of the L1 / L2-resident row, no per-element
+        // predicates (the scalar form below issued four predicated dword loads per chunk, each behind its own branch)
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 x4 = *reinterpret_cast<const float4*>(xr + c);
+            const float v[4] = {x4.x / den, x4.y / den, x4.z / den, x4.w / den};
+            if (yout) *reinterpret_cast<float4*>(yout + (size_t)row * d + c) = make_float4(v[0], v[1], v[2], v[3]);
+            if (img) {
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    h[t] = f32_to_bf16_bits(v[t]);
+                    l[t] = f32_to_bf16_bits(v[t] - bf16_bits_to_f32(h[t]));
+                }
+                const uint2 hv = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                if (layout == 3) {
+                    uint16_t* dst = img + (size_t)row * (2 * Kp) + (c >> 5) * 64 + (c & 31);
+                    const uint2 lv = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                    *reinterpret_cast<uint2*>(dst) = hv;
+                    *reinterpret_cast<uint2*>(dst + 32) = lv;
+                } else {
+                    *reinterpret_cast<uint2*>(img + (size_t)row * Kp + c) = hv;
+                }
+            }
+        }
+        return;
+    }
     // second sweep (the row is L1/L2 resident): write outputs
     for (int c = lane * 4; c < Kp; c += 256) {
         float v[4];
@@ -198,6 +225,53 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const uint16_t* __restric
     pairdist_epilogue<Cfg::FM, Cfg::FN>(acc, tm * Cfg::TM, tn * Cfg::TN, mb, nb, gsq, qsq, ng, nq, metric, out, blend);
 }
 
+// Epilogue of the persistent kernel for interior tiles: whole 128-byte lines per store instruction.  In the accumulator layout a store
+// instruction covers 16 query rows x 64 bytes (half a line per row); streamed non-temporally past the caches those halves reached memory as
+// partial-line writes (PMC WRITE_SIZE 5.50 GB per launch for a 4.00 GB result, round 3).  Here each wave passes its 64 x 64 sub-tile through a
+// PRIVATE 2 KiB strip of LDS behind the ring (3 x 48 + 8 x 2 = all 160 KiB of the CU) (the three ring stages are all busy during the epilogue: the producers are already fetching the
+// next tile), one block of 16 query rows x 32 gallery entries at a time: two ds_write_b128 per lane in the accumulator layout, two ds_read_b128 in
+// which 8 adjacent lanes hold one row's 128 bytes, two 16-byte stores of 8 rows x one full line each.  No workgroup barrier (the strip is the
+// wave's own; a wave's LDS operations execute in order), no registers live across the k-loop.
+constexpr int PAIR_STRIP_PITCH = 128;                         // bytes per staged row; 16-byte chunk c of row q sits at chunk c ^ (q & 7): the 8 lanes of a
+constexpr int PAIR_STRIP_BYTES = 16 * PAIR_STRIP_PITCH;       // ds_write_b128 group (8 rows, one chunk) land on 8 distinct bank quads
+__device__ __forceinline__ void pairdist_epilogue_lines(f32x4_t (&acc)[4][4], int g0w, int q0w, int lane, const float* __restrict__ gsq,
+                                                        const float* __restrict__ qsq, int ng, int metric, float* out, char* strip) {
+    // g0w / q0w: first gallery entry / query row of this wave's 64 x 64 sub-tile
+    char* wr = strip + (lane & 15) * PAIR_STRIP_PITCH;                            // + ((ii * 4 + (lane >> 4)) ^ (lane & 7)) * 16
+    const int wsw = lane & 7, wch = lane >> 4;
+    const char* rd = strip + (lane >> 3) * PAIR_STRIP_PITCH + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // + t * 8 * PITCH (rows + 8: same swizzle)
+    float* obase = out + (size_t)(q0w + (lane >> 3)) * ng + g0w + (lane & 7) * 4;
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float qq = 0.f;
+        if (metric == DALI_METRIC_L2SQ) qq = qsq[q0w + j * 16 + (lane & 15)];
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = ih * 2 + ii;
+                f32x4_t v;
+                if (metric == DALI_METRIC_L2SQ) {
+                    const float4 gg = *reinterpret_cast<const float4*>(gsq + g0w + i * 16 + (lane >> 4) * 4);
+                    v = f32x4_t{qq + gg.x - 2.0f * acc[i][j][0], qq + gg.y - 2.0f * acc[i][j][1], qq + gg.z - 2.0f * acc[i][j][2], qq + gg.w - 2.0f * acc[i][j][3]};
+                } else if (metric == DALI_METRIC_DOT) {
+                    v = acc[i][j];
+                } else {
+                    v = f32x4_t{1.0f - acc[i][j][0], 1.0f - acc[i][j][1], 1.0f - acc[i][j][2], 1.0f - acc[i][j][3]};
+                }
+                *reinterpret_cast<f32x4_t*>(wr + (((ii * 4 + wch) ^ wsw) << 4)) = v;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(rd + t * 8 * PAIR_STRIP_PITCH);
+                const f32x4_nt vv = {v[0], v[1], v[2], v[3]};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_nt*>(obase + (size_t)(j * 16 + t * 8) * ng + ih * 32));
+            }
+        }
+    }
+}
+
 // LDS-DMA version (what the launcher uses when the operands fit 32-bit buffer offsets): 128 gallery rows x 256 query
 // rows per 8-wave block (wave (wm, wn) of the 2 x 4 grid owns 64 x 64).  A k-step takes one 128-byte line of every operand
 // row ([hi 32 | lo 32] for NPROD = 3, 64 consecutive k for NPROD = 1) by buffer_load_dwordx4 ... lds (a DMA piece = 8 rows,
@@ -238,6 +312,8 @@ __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __re
     // apart would put each phase's stores under the others' MFMAs.  Refuted: 9.67 ms without, 10.1 - 10.5 ms with (bf16x3, 10k x 100k x 2048,
     // interleaved in one process; bf16 4.23 -> 4.30 - 5.5): the workgroups of an XCD walking neighbouring tiles AT THE SAME TIME is what keeps
     // their operand panels in that XCD's L2 (xcd_tile_map), and the stagger gives that up.  The stores' 8 us per tile are not burst contention.
+    // (round 4: a phase per XCD instead -- blockIdx.x & 7, the workgroups of one XCD in step, the eight XCDs' store bursts spread over a tile time --
+    // measured the same as no stagger: 8.69 / 8.73 / 8.72 ms at 1 / 2 / 3 sleep units against 8.72 without)
     for (int i = ((int)(blockIdx.x >> 3) & 7) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
     if (wave >= 8) {
         // ---- producer waves 8..15 (two per SIMD, next to two consumers): nothing but the DMA ring ----
@@ -326,7 +402,11 @@ __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __re
             __builtin_amdgcn_s_barrier();
             st_cur = (st_cur == 2) ? 0 : st_cur + 1;
         }
-        pairdist_epilogue<4, 4>(acc, tm * TM, tn * TN, wm * 64 + (lane >> 4) * 4, wn * 64 + (lane & 15), gsq, qsq, ng, nq, metric, out, blend);
+        if (!blend.on && (ng & 31) == 0 && (tm + 1) * TM <= ng && (tn + 1) * TN <= nq)
+            pairdist_epilogue_lines(acc, tm * TM + wm * 64, tn * TN + wn * 64, lane, gsq, qsq, ng, metric, out,
+                                    reinterpret_cast<char*>(smem + 3 * STAGE) + wave * PAIR_STRIP_BYTES);
+        else
+            pairdist_epilogue<4, 4>(acc, tm * TM, tn * TN, wm * 64 + (lane >> 4) * 4, wn * 64 + (lane & 15), gsq, qsq, ng, nq, metric, out, blend);
     }
 }
 
@@ -606,6 +686,150 @@ __global__ __launch_bounds__(256) void rank_reduce_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gallery-sharded ranking (the evaluation path over N GPUs): every rank holds the distances of ALL queries to ITS slice of
+// the gallery.  The position of a match in the full ranking is 1 + (kept gallery entries of every shard with a smaller key), keys being
+// (distance, GLOBAL gallery index), so the merge is a sum of per-shard counts:
+//   (1) rank_shard_matches_kernel: the keys of the query's matches inside this shard (identity slice of the shard's index, other camera);
+//   (2) [host: all-gather of the keys]
+//   (3) rank_shard_bins_kernel: all shards' match keys sorted in LDS (the same order on every rank: keys are unique); every kept entry of THIS
+//       shard is binned by the number of matches with a smaller key, exactly as rank_query_kernel bins the whole row;
+//   (4) [host: all-reduce SUM of the integer bins]
+//   (5) rank_shard_finish_kernel: positions = inclusive scan of the bins, AP and first-hit rank with rank_query_kernel's summation order
+//       (bit-identical to the single-GPU result), then rank_reduce_kernel.
+// Plain binary search over the sorted keys (no distance cells): this path is bounded by the collectives, not by the bins.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rank_shard_matches_kernel(const float* __restrict__ dist, const int32_t* __restrict__ q_pids,
+                                                                  const int32_t* __restrict__ q_cams, const int32_t* __restrict__ g_cams,
+                                                                  const int32_t* __restrict__ info, const int32_t* __restrict__ starts,
+                                                                  const int32_t* __restrict__ order, int ng, int g_offset, int cap,
+                                                                  unsigned long long* __restrict__ keys, int32_t* __restrict__ counts,
+                                                                  int32_t* __restrict__ status) {
+    __shared__ int s_n;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int lo = info[0], hi = info[1];
+    unsigned long long* krow = keys + (size_t)q * cap;
+    for (int t = tid; t < cap; t += 256) krow[t] = ~0ull;
+    if ((long long)hi - lo + 1 > RANK_MAX_PID_RANGE) { if (tid == 0) counts[q] = 0; return; }        // status 2 set by the index build
+    const int qp = q_pids[q], qc = q_cams[q];
+    int sb = 0, se = 0;
+    if (qp >= lo && qp <= hi) { sb = starts[qp - lo]; se = starts[qp - lo + 1]; }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const float* drow = dist + (size_t)q * ng;
+    for (int t = sb + tid; t < se; t += 256) {
+        const int g = order[t];
+        if (g_cams[g] != qc) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < cap) krow[slot] = rank_key(drow[g], g + g_offset);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        counts[q] = s_n < cap ? s_n : cap;
+        if (s_n > cap) atomicMax(status, 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_shard_bins_kernel(const float* __restrict__ dist, const int32_t* __restrict__ q_pids,
+                                                               const int32_t* __restrict__ q_cams, const int32_t* __restrict__ g_cams,
+                                                               const int32_t* __restrict__ info, const int32_t* __restrict__ starts,
+                                                               const int32_t* __restrict__ order, int nq, int ng, int g_offset,
+                                                               const unsigned long long* __restrict__ keys_all, const int32_t* __restrict__ counts_all,
+                                                               int world, int cap, int32_t* __restrict__ bins, int bins_cap,
+                                                               int32_t* __restrict__ status) {
+    __shared__ unsigned long long s_key[RANK_PMAX];
+    __shared__ int s_cnt[RANK_PMAX + 1];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int32_t* brow = bins + (size_t)q * (bins_cap + 1);
+    int np = 0;
+    for (int r = 0; r < world; ++r) np += counts_all[(size_t)r * nq + q];
+    if (np > bins_cap || np > RANK_PMAX) { if (tid == 0) atomicMax(status, 1); np = 0; }
+    for (int t = tid; t <= bins_cap; t += 256) brow[t] = 0;
+    if (np == 0) return;
+    // all shards' match keys of this query, in rank order (any order: they are sorted next)
+    int base = 0;
+    for (int r = 0; r < world; ++r) {
+        const int n = counts_all[(size_t)r * nq + q];
+        const unsigned long long* src = keys_all + ((size_t)r * nq + q) * cap;
+        for (int t = tid; t < n; t += 256) s_key[base + t] = src[t];
+        base += n;
+    }
+    int npad = 1;
+    while (npad < np) npad <<= 1;
+    for (int t = np + tid; t < npad; t += 256) s_key[t] = ~0ull;
+    for (int t = tid; t <= np; t += 256) s_cnt[t] = 0;
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < npad; t += 256) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const bool up = (t & k) == 0;
+                    const unsigned long long ka = s_key[t], kb = s_key[p];
+                    if (up ? kb < ka : ka < kb) { s_key[t] = kb; s_key[p] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned long long last_key = s_key[np - 1];
+    auto bin = [&](float d, int g, int delta) {
+        const unsigned long long k = rank_key(d, g + g_offset);
+        if (k > last_key) return;                                     // beyond the last match: affects no position
+        int p = 0, len = np;
+        while (len > 0) { const int half = len >> 1; if (s_key[p + half] < k) { p += half + 1; len -= half + 1; } else len = half; }
+        atomicAdd(&s_cnt[p], delta);
+    };
+    const float* drow = dist + (size_t)q * ng;
+    for (int g = tid; g < ng; g += 256) bin(drow[g], g, 1);
+    // junk of this shard (same identity, same camera) comes back out
+    const int lo = info[0], hi = info[1];
+    const int qp = q_pids[q], qc = q_cams[q];
+    if ((long long)hi - lo + 1 <= RANK_MAX_PID_RANGE && qp >= lo && qp <= hi) {
+        const int sb = starts[qp - lo], se = starts[qp - lo + 1];
+        __syncthreads();
+        for (int t = sb + tid; t < se; t += 256) { const int g = order[t]; if (g_cams[g] == qc) bin(drow[g], g, -1); }
+    }
+    __syncthreads();
+    for (int t = tid; t <= np; t += 256) brow[t] = s_cnt[t];
+}
+
+__global__ __launch_bounds__(256) void rank_shard_finish_kernel(const int32_t* __restrict__ bins, const int32_t* __restrict__ counts_all, int world,
+                                                                 int nq, int bins_cap, float* __restrict__ ap_out, int32_t* __restrict__ first_rank) {
+    __shared__ int s_scan[256];
+    __shared__ float s_red[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int np = 0;
+    for (int r = 0; r < world; ++r) np += counts_all[(size_t)r * nq + q];
+    if (np == 0 || np > bins_cap) { if (tid == 0) { ap_out[q] = 0.f; first_rank[q] = -1; } return; }
+    const int32_t* brow = bins + (size_t)q * (bins_cap + 1);
+    // inclusive scan of the bins + AP in sequential chunks of 256: the arithmetic and its order are rank_query_kernel's step 4
+    float ap_part = 0.f;
+    int carry = 0;
+    for (int base = 0; base < np; base += 256) {
+        const int t = base + tid;
+        const int v = (t < np) ? brow[t] : 0;
+        s_scan[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int add = (tid >= o) ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        const int pos = carry + s_scan[tid];
+        if (t < np) ap_part += (float)(t + 1) / (float)pos;
+        if (t == 0) first_rank[q] = pos - 1;
+        carry += s_scan[255];
+        __syncthreads();
+    }
+    ap_part = wave_sum(ap_part);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ap_part;
+    __syncthreads();
+    if (tid == 0) ap_out[q] = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)np;
+}
+
 }  // namespace dali
 
 using namespace dali;
@@ -642,7 +866,7 @@ static int launch_pairdist(int num_cus, hipStream_t st, const uint16_t* g_img, c
     if (!no_dma && (long long)ng * pitch * 2 < 0x7ff00000ll && (long long)nq * pitch * 2 < 0x7ff00000ll) {
         const int tm2 = (ng + 127) / 128, tn2 = (nq + 255) / 256;
         const int grid2 = xcd_tile_grid(tm2, tn2);
-        const int lds = 3 * (128 + 256) * 64 * 2;                                // 3 stages x 48 KiB
+        const int lds = 3 * (128 + 256) * 64 * 2 + 8 * PAIR_STRIP_BYTES;         // 3 stages x 48 KiB + the consumers' store strips = 160 KiB
         DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -757,6 +981,78 @@ extern "C" int dali_pairdist_blend(dali_ctx* ctx, void* stream, const float* Q, 
                            PairBlend{q_mag_prev, g_mag_prev, q_mag, g_mag, 1});
 }
 
+// gallery positions counting-sorted by identity (info = {min, max} pid; starts over [min, max]; order = positions grouped by pid)
+static int build_gallery_index(hipStream_t st, const int32_t* g_pids, int ng, int32_t* info, int32_t* counts, int32_t* starts, int32_t* cursor,
+                               int32_t* order, int32_t* status) {
+    const int32_t init[2] = {0x7fffffff, (int32_t)0x80000000};
+    DALI_HIP(hipMemcpyAsync(info, init, sizeof(init), hipMemcpyHostToDevice, st));
+    const int gb = (ng + 255) / 256 < 1024 ? (ng + 255) / 256 : 1024;
+    hipLaunchKernelGGL(rank_index_minmax_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info);
+    DALI_LAUNCH_CHECK();
+    DALI_HIP(hipMemsetAsync(counts, 0, ((size_t)RANK_MAX_PID_RANGE + 1) * 4, st));
+    hipLaunchKernelGGL(rank_index_count_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info, counts, status);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rank_index_scan_kernel, dim3(1), dim3(1024), 0, st, info, counts, starts, cursor);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rank_index_scatter_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info, starts, cursor, order);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+// the index of a gallery (shard) in the context workspace: -> info / starts / order
+static int shard_index(dali_ctx* ctx, hipStream_t st, const int32_t* g_pids, int ng, int32_t* status, int32_t*& info, int32_t*& starts, int32_t*& order) {
+    const size_t b_info = 256, b_order = align_up((size_t)ng * 4, 256), b_tab = align_up(((size_t)RANK_MAX_PID_RANGE + 1) * 4, 256);
+    char* ws = static_cast<char*>(workspace(ctx, b_info + b_order + 3 * b_tab));
+    if (!ws) return DALI_ERR_NOMEM;
+    info = reinterpret_cast<int32_t*>(ws);
+    order = reinterpret_cast<int32_t*>(ws + b_info);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + b_info + b_order);
+    starts = counts + b_tab / 4;
+    return build_gallery_index(st, g_pids, ng, info, counts, starts, starts + b_tab / 4, order, status);
+}
+
+extern "C" int dali_rank_shard_matches(dali_ctx* ctx, void* stream, const float* dist_shard, const int32_t* q_pids, const int32_t* g_pids,
+                                       const int32_t* q_camids, const int32_t* g_camids, int nq, int ng, int g_offset, int cap,
+                                       int64_t* keys, int32_t* counts, int32_t* status) {
+    DALI_REQUIRE(ctx && dist_shard && q_pids && g_pids && q_camids && g_camids && keys && counts && status, "dali_rank_shard_matches: null argument");
+    DALI_REQUIRE(nq > 0 && ng > 0 && g_offset >= 0 && cap > 0 && cap <= RANK_PMAX, "dali_rank_shard_matches: bad shape nq=%d ng=%d offset=%d cap=%d", nq, ng, g_offset, cap);
+    hipStream_t st = (hipStream_t)stream;
+    DALI_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    int32_t *info, *starts, *order;
+    if (int rc = shard_index(ctx, st, g_pids, ng, status, info, starts, order)) return rc;
+    hipLaunchKernelGGL(rank_shard_matches_kernel, dim3(nq), dim3(256), 0, st, dist_shard, q_pids, q_camids, g_camids, info, starts, order, ng, g_offset, cap,
+                       reinterpret_cast<unsigned long long*>(keys), counts, status);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+extern "C" int dali_rank_shard_bins(dali_ctx* ctx, void* stream, const float* dist_shard, const int32_t* q_pids, const int32_t* g_pids,
+                                    const int32_t* q_camids, const int32_t* g_camids, int nq, int ng, int g_offset, const int64_t* keys_all,
+                                    const int32_t* counts_all, int world, int cap, int32_t* bins, int bins_cap, int32_t* status) {
+    DALI_REQUIRE(ctx && dist_shard && q_pids && g_pids && q_camids && g_camids && keys_all && counts_all && bins && status, "dali_rank_shard_bins: null argument");
+    DALI_REQUIRE(nq > 0 && ng > 0 && g_offset >= 0 && world > 0 && cap > 0 && bins_cap > 0 && bins_cap <= RANK_PMAX,
+                 "dali_rank_shard_bins: bad shape nq=%d ng=%d world=%d cap=%d bins_cap=%d (<= %d)", nq, ng, world, cap, bins_cap, RANK_PMAX);
+    hipStream_t st = (hipStream_t)stream;
+    DALI_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    int32_t *info, *starts, *order;
+    if (int rc = shard_index(ctx, st, g_pids, ng, status, info, starts, order)) return rc;
+    hipLaunchKernelGGL(rank_shard_bins_kernel, dim3(nq), dim3(256), 0, st, dist_shard, q_pids, q_camids, g_camids, info, starts, order, nq, ng, g_offset,
+                       reinterpret_cast<const unsigned long long*>(keys_all), counts_all, world, cap, bins, bins_cap, status);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
+extern "C" int dali_rank_shard_finish(dali_ctx* ctx, void* stream, const int32_t* bins, const int32_t* counts_all, int world, int nq, int bins_cap,
+                                      int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid, float* ap, int32_t* first_rank) {
+    DALI_REQUIRE(ctx && bins && counts_all && cmc && mAP && num_valid && ap && first_rank, "dali_rank_shard_finish: null argument");
+    DALI_REQUIRE(nq > 0 && world > 0 && bins_cap > 0 && max_rank > 0 && max_rank <= 1024, "dali_rank_shard_finish: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rank_shard_finish_kernel, dim3(nq), dim3(256), 0, st, bins, counts_all, world, nq, bins_cap, ap, first_rank);
+    DALI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rank_reduce_kernel, dim3(1), dim3(256), 0, st, ap, first_rank, nq, max_rank, cmc, mAP, map64, num_valid);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
 extern "C" int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat, const int32_t* q_pids,
                               const int32_t* g_pids, const int32_t* q_camids, const int32_t* g_camids, int nq, int ng,
                               int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid, float* ap,
@@ -784,18 +1080,7 @@ extern "C" int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat,
         int32_t* counts = reinterpret_cast<int32_t*>(ws + head + b_info + b_order + b_pend);
         int32_t* starts = counts + b_tab / 4;
         int32_t* cursor = starts + b_tab / 4;
-        const int32_t init[2] = {0x7fffffff, (int32_t)0x80000000};
-        DALI_HIP(hipMemcpyAsync(info, init, sizeof(init), hipMemcpyHostToDevice, st));
-        const int gb = (ng + 255) / 256 < 1024 ? (ng + 255) / 256 : 1024;
-        hipLaunchKernelGGL(rank_index_minmax_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info);
-        DALI_LAUNCH_CHECK();
-        DALI_HIP(hipMemsetAsync(counts, 0, ((size_t)RANK_MAX_PID_RANGE + 1) * 4, st));
-        hipLaunchKernelGGL(rank_index_count_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info, counts, status);
-        DALI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(rank_index_scan_kernel, dim3(1), dim3(1024), 0, st, info, counts, starts, cursor);
-        DALI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(rank_index_scatter_kernel, dim3(gb), dim3(256), 0, st, g_pids, ng, info, starts, cursor, order);
-        DALI_LAUNCH_CHECK();
+        if (int rc = build_gallery_index(st, g_pids, ng, info, counts, starts, cursor, order, status)) return rc;
         hipLaunchKernelGGL((rank_query_kernel<RANK_PSMALL, 0>), dim3(nq), dim3(256), 0, st, distmat, q_pids, q_camids, g_camids, info, starts, order,
                            nq, ng, ap_buf, fr_buf, pending, status);
         DALI_LAUNCH_CHECK();

@@ -64,10 +64,21 @@ def extractFeatures(subset, img_height, img_width, model, batch_size, gpu_index=
     start = time.time()
     chunks = []
     turb = None if not turbulance_dir_path else (turbulance_dir_path, turb_strength, dataset)
+    starts = list(range(0, len(paths), batch_size))
+    batched = all(hasattr(_loader, a) for a in ("plan", "submit", "finish"))        # transforms.gpu_eval_loader: decode pool + one launch per batch
     with torch.no_grad():
-        for b in range(0, len(paths), batch_size):
-            batch = _loader(paths[b:b + batch_size], img_height, img_width, turb)
-            chunks.append(model(batch.to(dev, non_blocking=True)))
+        if batched:
+            # batch i + 1 decodes on the pool while batch i's forward is enqueued and runs; its resize + normalise go to a side stream
+            ahead = [_loader.submit(_loader.plan(paths[b:b + batch_size], img_height, img_width, turb)) for b in starts[:1]]
+            for i in range(len(starts)):
+                if i + 1 < len(starts):
+                    b = starts[i + 1]
+                    ahead.append(_loader.submit(_loader.plan(paths[b:b + batch_size], img_height, img_width, turb)))
+                chunks.append(model(_loader.finish(ahead.pop(0), dev)))
+        else:
+            for b in starts:
+                batch = _loader(paths[b:b + batch_size], img_height, img_width, turb)
+                chunks.append(model(batch.to(dev, non_blocking=True)))
     fvs = torch.cat(chunks, 0) if chunks else torch.empty(0, 0, device=dev)
     if not keep_on_device:
         fvs = fvs.cpu()

@@ -119,6 +119,116 @@ def rank_eval(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, return_p
     return res
 
 
+RANK_PMAX = 4096          # matches + junk of one query the ranking kernels hold in LDS (csrc/eval.hip)
+
+
+def shard_bounds(n, world):
+    """Contiguous gallery slices of (almost) equal size, multiples of 128 rows (the distance kernel's gallery tile) where possible:
+    -> list of world + 1 offsets."""
+    per = -(-n // world)
+    per = -(-per // 128) * 128
+    return [min(r * per, n) for r in range(world + 1)]
+
+
+def rank_shard_matches(dist_shard, qp, gp, qc, gc, g_offset, cap):
+    """Step 1 (device, int32 code tensors): -> (keys int64 [nq, cap], counts int32 [nq], status int32 [1])."""
+    nq, ng = dist_shard.shape
+    dev = dist_shard.device
+    keys = torch.full((nq, cap), -1, device=dev, dtype=torch.int64)
+    counts = torch.zeros(nq, device=dev, dtype=torch.int32)
+    status = torch.zeros(1, device=dev, dtype=torch.int32)
+    if ng > 0:
+        _lib.check(_lib.lib().dali_rank_shard_matches(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(dist_shard, torch.float32, "dist_shard"),
+                                                       _lib.ptr(qp, torch.int32), _lib.ptr(gp, torch.int32), _lib.ptr(qc, torch.int32),
+                                                       _lib.ptr(gc, torch.int32), nq, ng, int(g_offset), cap, _lib.ptr(keys), _lib.ptr(counts),
+                                                       _lib.ptr(status)), "dali_rank_shard_matches")
+    return keys, counts, status
+
+
+def rank_shard_bins(dist_shard, qp, gp, qc, gc, g_offset, keys_all, counts_all, bins_cap):
+    """Step 3: keys_all int64 [world, nq, cap], counts_all int32 [world, nq] (all shards, rank-major) -> (bins int32 [nq, bins_cap + 1], status)."""
+    nq, ng = dist_shard.shape
+    dev = dist_shard.device
+    world, _, cap = keys_all.shape
+    bins = torch.zeros(nq, bins_cap + 1, device=dev, dtype=torch.int32)
+    status = torch.zeros(1, device=dev, dtype=torch.int32)
+    if ng > 0:
+        _lib.check(_lib.lib().dali_rank_shard_bins(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(dist_shard, torch.float32, "dist_shard"),
+                                                    _lib.ptr(qp, torch.int32), _lib.ptr(gp, torch.int32), _lib.ptr(qc, torch.int32),
+                                                    _lib.ptr(gc, torch.int32), nq, ng, int(g_offset), _lib.ptr(keys_all.contiguous(), torch.int64),
+                                                    _lib.ptr(counts_all.contiguous(), torch.int32), world, cap, _lib.ptr(bins), bins_cap,
+                                                    _lib.ptr(status)), "dali_rank_shard_bins")
+    return bins, status
+
+
+def rank_shard_finish(bins, counts_all, max_rank):
+    """Step 5: the SUMMED bins -> dict of device tensors (cmc, mAP, map64, nvalid, ap, first_rank)."""
+    dev = bins.device
+    nq, bins_cap = bins.shape[0], bins.shape[1] - 1
+    o = dict(cmc=torch.empty(max_rank, device=dev, dtype=torch.float32), mAP=torch.empty(1, device=dev, dtype=torch.float32),
+             map64=torch.empty(1, device=dev, dtype=torch.float64), nvalid=torch.empty(1, device=dev, dtype=torch.int32),
+             ap=torch.empty(nq, device=dev, dtype=torch.float32), first_rank=torch.empty(nq, device=dev, dtype=torch.int32))
+    _lib.check(_lib.lib().dali_rank_shard_finish(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(bins.contiguous(), torch.int32),
+                                                  _lib.ptr(counts_all.contiguous(), torch.int32), counts_all.shape[0], nq, bins_cap, max_rank,
+                                                  _lib.ptr(o["cmc"]), _lib.ptr(o["mAP"]), _lib.ptr(o["map64"]), _lib.ptr(o["nvalid"]),
+                                                  _lib.ptr(o["ap"]), _lib.ptr(o["first_rank"])), "dali_rank_shard_finish")
+    return o
+
+
+def rank_eval_sharded(dist_shard, q_pids, g_pids_shard, q_camids, g_camids_shard, g_offset, group=None, max_rank=50, ng_total=None,
+                      return_per_query=False):
+    """market1501 CMC / mAP with the GALLERY sharded over the ranks of ``group`` (validateModels.py:41-47,61-69): this rank
+    holds ``dist_shard`` [nq, ng_local] = all queries against its gallery slice, whose first entry has global index ``g_offset``.  Every
+    rank passes all query ids and ITS slice of the gallery ids.  Two collectives: an all-gather of the per-query match keys (8 bytes per
+    match) and an all-reduce (SUM) of integer bins; the result is bit-identical to ``rank_eval`` on the whole matrix and the same on
+    every rank.  -> (cmc numpy float32 [max_rank], mAP float)"""
+    import torch.distributed as dist
+    dev = dist_shard.device
+    nq, ng = dist_shard.shape
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    qp, gp = factorize_ids(q_pids, g_pids_shard)                 # codes only need to agree between q and g on THIS rank
+    qc, gc = factorize_ids(q_camids, g_camids_shard)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    codes = (t(qp), t(gp), t(qc), t(gc))
+    # cap: the largest identity of any shard (an upper bound of a query's matches inside one shard), agreed over the ranks
+    caps = torch.tensor([int(np.bincount(gp).max()) if ng > 0 else 1, ng], dtype=torch.int64, device=dev)
+    if world > 1:
+        gathered = [torch.empty_like(caps) for _ in range(world)]
+        dist.all_gather(gathered, caps, group=group)
+        cap, ng_all = int(max(int(c[0]) for c in gathered)), int(sum(int(c[1]) for c in gathered))
+    else:
+        cap, ng_all = int(caps[0]), ng
+    if ng_total is not None and ng_all != ng_total:
+        raise _lib.DaliError("rank_eval_sharded: the gallery shards hold %d entries, expected %d" % (ng_all, ng_total))
+    cap = max(1, min(cap, RANK_PMAX))
+    bins_cap = min(world * cap, RANK_PMAX)
+    keys, counts, st1 = rank_shard_matches(dist_shard, *codes, g_offset, cap)
+    if world > 1:
+        keys_l = [torch.empty_like(keys) for _ in range(world)]
+        counts_l = [torch.empty_like(counts) for _ in range(world)]
+        dist.all_gather(keys_l, keys, group=group)
+        dist.all_gather(counts_l, counts, group=group)
+        keys_all, counts_all = torch.stack(keys_l), torch.stack(counts_l)
+    else:
+        keys_all, counts_all = keys.unsqueeze(0), counts.unsqueeze(0)
+    bins, st2 = rank_shard_bins(dist_shard, *codes, g_offset, keys_all, counts_all, bins_cap)
+    status = torch.maximum(st1, st2)
+    if world > 1:
+        dist.all_reduce(bins, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(status, op=dist.ReduceOp.MAX, group=group)
+    o = rank_shard_finish(bins, counts_all, min(max_rank, ng_all))
+    stv = int(status.item())
+    if stv != 0:
+        raise _lib.DaliError("rank_eval_sharded: " + ("a query has more than %d matches (documented limit)" % RANK_PMAX if stv == 1 else
+                                                      "identity codes span more than 2^20 values (documented limit)"))
+    if int(o["nvalid"].item()) == 0:
+        raise AssertionError("Error: all query identities do not appear in gallery")
+    res = (o["cmc"].cpu().numpy(), float(o["map64"].item()))
+    if return_per_query:
+        return res + (o["ap"].cpu().numpy(), o["first_rank"].cpu().numpy())
+    return res
+
+
 def class_targets(fvs, order, bounds, first_pick, num_proxies=5):
     """Class centers + farthest-point proxies in one launch (train_encodersKIT.py:113-156, :252-284).
     fvs [N,D] fp32 CUDA; order [N] int32 (rows sorted by identity), bounds [NC+1] int32, first_pick [NC] int32 (position

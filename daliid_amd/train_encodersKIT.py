@@ -112,6 +112,40 @@ class samplePKBatches:
             dist = np.stack((np.zeros(len(sel), dtype=np.int32), strengths.astype(np.int32)), 1).reshape(-1)
         return imgs, torch.ones(imgs.shape[0]) * float(pid), dist
 
+    def plan(self, idx, loader):
+        """``__getitem__`` with the image work deferred: the same numpy / torch draws in the same order (selection, the clean images'
+        augmentation parameters, strengths, each distorted image's parameters), but the files are only LISTED -- in the final
+        (clean, distorted, clean, distorted ...) order -- so that a whole PK batch is decoded on the pool and resized + augmented by one
+        launch each (``plan_batch`` / ``finish_batch``).  -> (ImagePlan, labels tensor, distortion levels)"""
+        from .transforms import ImagePlan
+        pid = self.labels_set[idx]
+        names = self.images_names[self.labels == pid]
+        sel = np.random.choice(names.shape[0], size=min(names.shape[0], self.K), replace=False)
+        clean = loader.plan(list(names[sel]), self.img_height, self.img_width, None)
+        if self.kind_of_transform == 0:
+            plan, dist = clean, np.zeros(len(sel), dtype=np.int32)
+        else:
+            strengths = np.random.choice([1, 2, 3, 4, 5], size=len(sel))
+            turb = [loader.plan([names[s]], self.img_height, self.img_width, (self.turbulance_dir_path, int(t), self.dataset))
+                    for s, t in zip(sel, strengths)]
+            k = len(sel)
+            order = [j for i in range(k) for j in (i, k + i)]                          # clean_0, turb_0, clean_1, turb_1, ...
+            plan = ImagePlan.concat([clean] + turb, order)
+            dist = np.stack((np.zeros(k, dtype=np.int32), strengths.astype(np.int32)), 1).reshape(-1)
+        return plan, torch.ones(len(plan.files)) * float(pid), dist
+
+    def plan_batch(self, ids, loader):
+        """Plans of the identities ``ids`` merged into one and submitted to the decode pool.  -> ticket for ``finish_batch``"""
+        from .transforms import ImagePlan
+        parts = [self.plan(i, loader) for i in ids]
+        ticket = loader.submit(ImagePlan.concat([p[0] for p in parts]))
+        return ticket, torch.cat([p[1] for p in parts], 0), np.concatenate([p[2] for p in parts])
+
+    @staticmethod
+    def finish_batch(planned, loader, dev):
+        ticket, labels, dist = planned
+        return loader.finish(ticket, dev), labels, dist
+
 
 class trainer(object):
     """train_encodersKIT.py:45-249, same constructor arguments and attributes."""
@@ -133,6 +167,7 @@ class trainer(object):
         self._mom = getattr(model_momentum, "module", model_momentum)
         self._adam = optimizer if isinstance(optimizer, optim.FusedAdam) else optim.FusedAdam.from_torch(optimizer, self._net)
         self._dp = None                      # parallel.GradReducer, built at the first step (needs the plan's stage ranges)
+        self.prefetch_depth = 2              # PK batches planned + decoding ahead of the one being trained on (batched loaders only)
         self.last_epoch_stats = None
 
     # ---- epoch-level: inference over the train set, centers, proxies (train_encodersKIT.py:104-156) ----
@@ -200,16 +235,29 @@ class trainer(object):
                 order = parallel.broadcast_from_rank0(order, self.process_group)
             n_batches = len(order) // bs
             acc = torch.zeros(6, device=dev, dtype=torch.float32)
-            for b in range(n_batches):
+            def batch_ids(b):
                 ids = order[b * bs:(b + 1) * bs]
-                if world:
-                    ids = parallel.shard_identities(ids, rank, world)
-                parts = [event_dataset[i] for i in ids]
-                batch_imgs = torch.cat([p[0] for p in parts], 0).to(dev, non_blocking=True)
+                return parallel.shard_identities(ids, rank, world) if world else ids
+            # Loaders with the batched protocol (transforms.gpu_train_loader): batch b + 1 and b + 2 are planned (their random draws made, in
+            # batch order) and decoding on the pool while step b is enqueued and runs; one resize + one augment launch per batch on a side
+            # stream.  Other loaders (synthetic tensors in memory) keep the per-identity calls.
+            loader = get_train_loader()
+            batched = all(hasattr(loader, a) for a in ("plan", "submit", "finish"))
+            pending = []
+            nxt = 0
+            for b in range(n_batches):
+                if batched:
+                    while nxt < n_batches and len(pending) < 1 + self.prefetch_depth:
+                        pending.append(event_dataset.plan_batch(batch_ids(nxt), loader)); nxt += 1
+                    batch_imgs, labels_f, dist_np = event_dataset.finish_batch(pending.pop(0), loader, dev)
+                else:
+                    parts = [event_dataset[i] for i in batch_ids(b)]
+                    batch_imgs = torch.cat([p[0] for p in parts], 0).to(dev, non_blocking=True)
+                    labels_f, dist_np = torch.cat([p[1] for p in parts], 0), np.concatenate([p[2] for p in parts])
                 if not world and batch_imgs.shape[0] <= 2:                            # :194-195 (never under DP: the global batch has
                     continue                                                          # >= 3 identities, and a skip must be collective)
-                labels_codes = _codes(torch.cat([p[1] for p in parts], 0), dev)
-                w = _sample_weights(torch.from_numpy(np.concatenate([p[2] for p in parts])), current_epoch, self.number_of_epoches, dev)
+                labels_codes = _codes(labels_f, dev)
+                w = _sample_weights(torch.from_numpy(dist_np), current_epoch, self.number_of_epoches, dev)
                 self.train_step(heads, batch_imgs, labels_codes, w, acc)
             a = acc.cpu().numpy()                                                      # the only host sync of the epoch
             nb = max(n_batches, 1)

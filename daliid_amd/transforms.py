@@ -171,9 +171,40 @@ def augment(images_u8, params, mean=IMAGENET_MEAN, std=IMAGENET_STD):
 
 
 # ---- loaders that plug into getFeatures.set_image_loader / train_encodersKIT.set_train_loader -------------------------
-def _decode(paths):
+# Host side of the pipeline (the reference: torch DataLoader with 8 worker processes, train_encodersKIT.py:77-83, getFeatures.py:52).
+# JPEG decode is the host's share: PIL releases the GIL while it decodes, so a thread pool scales with the cores, and a batch is
+# SUBMITTED (its files start decoding) before the previous batch's GPU work is enqueued and FINISHED (one packed upload, ONE
+# dali_resize_bicubic_u8 + ONE dali_augment_batch launch for the whole batch, on a side stream) when it is needed:
+#     ticket = loader.submit(plan)   ...   images = loader.finish(ticket)
+# Random augmentation parameters are drawn at PLAN time, on the calling thread, in the order the sequential per-call path draws
+# them, so the batched path reproduces it bit for bit.
+_pool = None
+_side = {}
+
+
+def decode_pool():
+    """The process-wide decode pool: DALIID_DECODE_THREADS threads (default: the CPUs this process may run on, at most 16)."""
+    global _pool
+    if _pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        _pool = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("DALIID_DECODE_THREADS", min(16, ncpu)))), thread_name_prefix="dali-decode")
+    return _pool
+
+
+def _decode_one(path):
     from PIL import Image
-    return [np.asarray(Image.open(p).convert("RGB")) for p in paths]          # torchreid.utils.tools.read_image
+    return np.asarray(Image.open(path).convert("RGB"))                        # torchreid.utils.tools.read_image
+
+
+def _decode(paths):
+    if len(paths) <= 2:
+        return [_decode_one(p) for p in paths]
+    return list(decode_pool().map(_decode_one, paths))
 
 
 def _turb_path(path, turb):
@@ -181,15 +212,83 @@ def _turb_path(path, turb):
     return turb_path(path, turb)
 
 
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=dev)
+    return _side[key]
+
+
+class ImagePlan:
+    """What one loader call would do, with every random draw already made: files to decode + their [n,16] parameter rows."""
+    __slots__ = ("files", "params", "height", "width")
+
+    def __init__(self, files, params, height, width):
+        self.files, self.params, self.height, self.width = files, params, height, width
+
+    @staticmethod
+    def concat(plans, order=None):
+        """One plan for many (all of one output size); ``order``: permutation of the concatenated images (the final batch order)."""
+        files = [f for p in plans for f in p.files]
+        params = np.concatenate([p.params for p in plans], 0) if plans else np.zeros((0, AUG_WORDS), np.int32)
+        if order is not None:
+            files, params = [files[i] for i in order], params[np.asarray(order)]
+        return ImagePlan(files, params, plans[0].height, plans[0].width)
+
+
+class _Ticket:
+    __slots__ = ("plan", "futures")
+
+    def __init__(self, plan, futures):
+        self.plan, self.futures = plan, futures
+
+
+def submit(plan, decode=None):
+    """Start decoding the plan's files on the pool (returns at once)."""
+    fn = decode or _decode_one
+    return _Ticket(plan, [decode_pool().submit(fn, f) for f in plan.files])
+
+
+def finish(ticket, device=None, side_stream=True):
+    """Wait for the decodes, then ONE resize launch + ONE augment launch for the whole plan.  With ``side_stream`` the upload and the two
+    kernels run on the device's side stream (under whatever the current stream is computing) and the current stream waits for them."""
+    arrs = [f.result() for f in ticket.futures]
+    plan = ticket.plan
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if not side_stream:
+        return augment(resize_bicubic_u8(arrs, plan.height, plan.width, dev), plan.params)
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    with torch.cuda.stream(side):
+        u8 = resize_bicubic_u8(arrs, plan.height, plan.width, dev)
+        out = augment(u8, plan.params)
+    main.wait_stream(side)
+    out.record_stream(main)
+    return out
+
+
+def plan_eval(paths, img_height, img_width, turb=None):
+    files = [_turb_path(p, turb) for p in paths] if turb else list(paths)
+    return ImagePlan(files, eval_params(len(files)), img_height, img_width)
+
+
+def plan_train(paths, img_height, img_width, turb=None):
+    files = [_turb_path(p, turb) for p in paths] if turb else list(paths)
+    return ImagePlan(files, sample_train_params(len(files), img_height, img_width), img_height, img_width)
+
+
 def gpu_eval_loader(paths, img_height, img_width, turb=None, decode=_decode):
     """getFeatures.sample.__getitem__ for a list of paths: decode (host) -> bicubic resize -> ToTensor -> Normalize (GPU)."""
-    files = [_turb_path(p, turb) for p in paths] if turb else list(paths)
-    u8 = resize_bicubic_u8(decode(files), img_height, img_width)
-    return augment(u8, eval_params(len(files)))
+    plan = plan_eval(paths, img_height, img_width, turb)
+    return augment(resize_bicubic_u8(decode(plan.files), img_height, img_width), plan.params)
 
 
 def gpu_train_loader(paths, img_height, img_width, turb=None, decode=_decode):
     """samplePKBatches.transform for a list of paths (train_encodersKIT.py:313-320)."""
-    files = [_turb_path(p, turb) for p in paths] if turb else list(paths)
-    u8 = resize_bicubic_u8(decode(files), img_height, img_width)
-    return augment(u8, sample_train_params(len(files), img_height, img_width))
+    plan = plan_train(paths, img_height, img_width, turb)
+    return augment(resize_bicubic_u8(decode(plan.files), img_height, img_width), plan.params)
+
+
+# the batched protocol of the two loaders (train_encodersKIT.samplePKBatches.plan / getFeatures.extractFeatures use it when present)
+gpu_eval_loader.plan, gpu_eval_loader.submit, gpu_eval_loader.finish = plan_eval, submit, finish
+gpu_train_loader.plan, gpu_train_loader.submit, gpu_train_loader.finish = plan_train, submit, finish

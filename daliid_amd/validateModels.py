@@ -29,6 +29,24 @@ class validateModels:
         cmc, mAP = self.calculateMetrics(distmat, queries, gallery)
         return cmc, mAP, (distmat.cpu() if self.distmat_on_cpu else distmat)
 
+    def validate_sharded(self, queries, gallery, model, process_group=None):
+        """``validate`` with the gallery split over the ranks of ``process_group`` (one process per GPU): every rank extracts
+        the query features and the features of ITS contiguous gallery slice, computes its [Nq, Ng / N] block of ``1 - q @ g.T`` and the
+        ranks merge per-query hit counts (ops_eval.rank_eval_sharded: one all-gather of match keys, one all-reduce of integer bins).
+        -> (cmc, mAP, this rank's distance block); cmc / mAP are identical on every rank and equal to the single-GPU result bit for bit."""
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        model.eval()
+        lo, hi = ops_eval.shard_bounds(len(gallery), world)[rank:rank + 2]
+        queries_fvs = extractFeatures(queries, self.img_height, self.img_width, model, 500, self.gpu_index, keep_on_device=True)
+        gallery_fvs = extractFeatures(gallery[lo:hi], self.img_height, self.img_width, model, 500, self.gpu_index, keep_on_device=True)
+        block = self.distance(queries_fvs, gallery_fvs)
+        del queries_fvs, gallery_fvs
+        cmc, mAP = ops_eval.rank_eval_sharded(block, queries[:, 1], gallery[lo:hi, 1], queries[:, 2], gallery[lo:hi, 2], lo, process_group,
+                                              max_rank=50, ng_total=len(gallery))
+        return cmc, mAP, block
+
     def distance(self, queries_fvs, gallery_fvs):
         """validateModels.py:41-47: q/|q|, g/|g|, 1 - q @ g.T (fused)."""
         return ops_eval.pairdist(queries_fvs.contiguous(), gallery_fvs.contiguous(), metric="cosine", precision=self.precision, normalize=True)

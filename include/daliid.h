@@ -108,6 +108,25 @@ int dali_rank_eval(dali_ctx* ctx, void* stream, const float* distmat, const int3
                    int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid,
                    float* ap, int32_t* first_rank, int32_t* status);
 
+/* Gallery-sharded evaluation over N ranks (validateModels.py:41-47,61-69 with the gallery split across GPUs): each rank holds
+ * dist_shard [nq][ng] = the distances of ALL queries to ITS gallery slice, whose first entry has global index g_offset.  Three calls with
+ * two collectives of the caller's between them (the mirror: ops_eval.rank_eval_sharded over torch.distributed):
+ *   dali_rank_shard_matches -> keys [nq][cap] int64 ((orderable distance bits << 32) | global gallery index; unused slots ~0) and counts [nq]
+ *                              of the query's matches inside this shard;            [all-gather keys and counts: rank-major]
+ *   dali_rank_shard_bins    -> bins [nq][bins_cap + 1] int32: this shard's kept entries binned by the number of matches (of all shards) with a
+ *                              smaller key;                                         [all-reduce SUM of bins]
+ *   dali_rank_shard_finish  -> cmc / mAP / per-query ap + first_rank from the summed bins; bit-identical to dali_rank_eval on the whole matrix.
+ * cap: an upper bound of a query's matches inside one shard, the same on every rank; bins_cap >= a query's matches over all shards
+ * (<= 4096).  status[0] = 1 when either bound is exceeded, 2 as for dali_rank_eval. */
+int dali_rank_shard_matches(dali_ctx* ctx, void* stream, const float* dist_shard, const int32_t* q_pids, const int32_t* g_pids,
+                            const int32_t* q_camids, const int32_t* g_camids, int nq, int ng, int g_offset, int cap,
+                            int64_t* keys, int32_t* counts, int32_t* status);
+int dali_rank_shard_bins(dali_ctx* ctx, void* stream, const float* dist_shard, const int32_t* q_pids, const int32_t* g_pids,
+                         const int32_t* q_camids, const int32_t* g_camids, int nq, int ng, int g_offset, const int64_t* keys_all,
+                         const int32_t* counts_all, int world, int cap, int32_t* bins, int bins_cap, int32_t* status);
+int dali_rank_shard_finish(dali_ctx* ctx, void* stream, const int32_t* bins, const int32_t* counts_all, int world, int nq, int bins_cap,
+                           int max_rank, float* cmc, float* mAP, double* map64, int32_t* num_valid, float* ap, int32_t* first_rank);
+
 /* ---- training path: Encoders.ResNet50ReID trunk (Encoders.py:330-339) ----------------------------- *
  * Single-op entry points (the parity tests call these; the net plan below chains the same kernels).
  * Layouts: activations NHWC bf16; forward weights [cout][r][s][cin] bf16; dgrad weights

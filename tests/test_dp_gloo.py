@@ -112,3 +112,13 @@ def test_shard_identities_validation():
     assert list(parallel.shard_identities(np.arange(16), 3, 8)) == [6, 7]
     with pytest.raises(ValueError):
         parallel.shard_identities(np.arange(10), 0, 4)
+
+
+def test_gallery_shard_bounds_cover_the_gallery_once():
+    """ops_eval.shard_bounds (the gallery split of validate_sharded): contiguous, disjoint, complete, 128-row aligned starts; trailing
+    shards may be empty."""
+    from daliid_amd import ops_eval
+    for n, world in [(100000, 8), (15913, 8), (300, 8), (168, 2), (1, 4), (128, 1)]:
+        b = ops_eval.shard_bounds(n, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == n
+        assert all(b[i] <= b[i + 1] for i in range(world)) and all(x % 128 == 0 or x == n for x in b)

@@ -33,10 +33,12 @@ def test_l2norm_rows_fwd_bwd(ops, n, d, eps):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("nq,ng,d", [(1, 5, 32), (130, 259, 96), (3, 1031, 64), (129, 128, 160)])
+@pytest.mark.parametrize("nq,ng,d", [(1, 5, 32), (130, 259, 96), (3, 1031, 64), (129, 128, 160), (520, 416, 96), (768, 1280, 64)])
 def test_pairdist_exact_on_small_integers(ops, prec, nq, ng, d):
     """Small integers are exact in bf16 and their dot products exact in fp32: the MFMA fragment layout,
-    the LDS swizzle, the XCD tile map and every edge tile must reproduce the oracle BIT-EXACTLY."""
+    the LDS swizzle, the XCD tile map and every edge tile must reproduce the oracle BIT-EXACTLY.
+    (520, 416) and (768, 1280) have INTERIOR 128 x 256 tiles (and ng % 32 == 0): those leave through the persistent kernel's
+    line-staged store (pairdist_epilogue_lines), the others through the per-lane epilogue of the edge tiles."""
     g = torch.Generator().manual_seed(nq + 7 * ng + d)
     q = torch.randint(-3, 4, (nq, d), generator=g).float()
     gal = torch.randint(-3, 4, (ng, d), generator=g).float()
@@ -213,3 +215,42 @@ def test_config5_rank_eval_full_size_properties(ops):
     assert abs(mAP2 - 1.0) < 1e-6 and abs(cmc2[0] - 1.0) < 1e-6
     del dist
     torch.cuda.empty_cache()
+
+
+# ---- gallery-sharded ranking: bins summed over shards == the single-GPU ranking, bit for bit --------------------------
+def _shard_case(seed, nq, ng, n_ids, n_cams, ties):
+    rng = np.random.default_rng(seed)
+    q_pids = rng.integers(0, n_ids, nq); g_pids = rng.integers(0, n_ids, ng)
+    q_pids[:3] = n_ids + 5                                   # queries whose identity is not in the gallery at all: invalid
+    q_cams = rng.integers(0, n_cams, nq); g_cams = rng.integers(0, n_cams, ng)
+    d = rng.random((nq, ng), dtype=np.float32)
+    if ties:
+        d = np.round(d * 20) / 20                            # many exact ties: ordered by GLOBAL gallery index
+    return torch.from_numpy(d), q_pids.astype(str), g_pids.astype(str), q_cams.astype(str), g_cams.astype(str)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("nq,ng,n_ids,ties", [(37, 1000, 11, False), (64, 5000, 40, True), (5, 300, 2, True)])
+def test_sharded_ranking_equals_whole_gallery_ranking(ops, world, nq, ng, n_ids, ties):
+    """The three device steps of rank_eval_sharded run for every shard in ONE process (the two collectives replaced by a stack and a sum):
+    per-query AP, first-hit rank, CMC and mAP must equal dali_rank_eval's on the whole matrix bit for bit -- string ids, junk removal,
+    invalid queries, exact ties, an empty last shard (world 8 on 300 entries = 128-row slices) included."""
+    dist, qp_s, gp_s, qc_s, gc_s = _shard_case(nq + ng, nq, ng, n_ids, 3, ties)
+    D = dist.cuda()
+    cmc_ref, map_ref, ap_ref, fr_ref = ops.rank_eval(D, qp_s, gp_s, qc_s, gc_s, max_rank=50, return_per_query=True)
+    bounds = ops.shard_bounds(ng, world)
+    t = lambda a: torch.from_numpy(a).cuda()
+    shards = []
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        qp, gp = ops.factorize_ids(qp_s, gp_s[lo:hi]); qc, gc = ops.factorize_ids(qc_s, gc_s[lo:hi])
+        shards.append((D[:, lo:hi].contiguous(), t(qp), t(gp), t(qc), t(gc), lo))
+    cap = max(int(np.unique(gp_s[bounds[r]:bounds[r + 1]], return_counts=True)[1].max()) if bounds[r + 1] > bounds[r] else 1 for r in range(world))
+    ks, cs = zip(*[ops.rank_shard_matches(*sh, cap)[:2] for sh in shards])
+    keys_all, counts_all = torch.stack(ks), torch.stack(cs)
+    bins_cap = min(world * cap, ops.RANK_PMAX)
+    bins = sum(ops.rank_shard_bins(*sh, keys_all, counts_all, bins_cap)[0] for sh in shards)
+    o = ops.rank_shard_finish(bins, counts_all, min(50, ng))
+    assert np.array_equal(o["ap"].cpu().numpy(), ap_ref) and np.array_equal(o["first_rank"].cpu().numpy(), fr_ref)
+    assert np.array_equal(o["cmc"].cpu().numpy(), cmc_ref) and float(o["map64"].item()) == map_ref
+    assert (fr_ref[:3] == -1).all() and (fr_ref[3:] >= 0).any()

@@ -94,3 +94,105 @@ def test_loaders_plug_into_the_mirrors(T, tmp_path):
     finally:
         getFeatures.set_image_loader(None)
         train_encodersKIT.set_train_loader(None)
+
+
+def _write_dataset(tmp_path, n_ids, per_id, hw=(128, 64), turb=True, fmt="jpg"):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    clean = tmp_path / "clean"; tdir = tmp_path / "turb"
+    clean.mkdir(); tdir.mkdir()
+    records = []
+    for pid in range(n_ids):
+        for k, im in enumerate(_images(rng, [hw] * per_id)):
+            name = "%04d_c1s1_%06d_00" % (pid, k)
+            Image.fromarray(im).save(str(clean / (name + "." + fmt)), quality=95)
+            if turb:
+                for s in range(1, 6):
+                    Image.fromarray(np.roll(im, s, axis=1)).save(str(tdir / ("%s_turbstrength%d.jpg" % (name, s))), quality=95)
+            records.append([str(clean / (name + "." + fmt)), str(pid), "0", "person"])
+    return np.array(records), str(tdir)
+
+
+def test_batched_pk_batch_equals_the_per_identity_calls(T, tmp_path):
+    """One PK batch through plan_batch / finish_batch (decode pool, ONE resize + ONE augment launch for the whole batch, side stream)
+    against the per-identity, per-distorted-image loader calls of samplePKBatches.__getitem__ (train_encodersKIT.py:365-400): same numpy /
+    torch draws in the same order, so the tensors, labels and distortion levels are identical bit for bit."""
+    from daliid_amd import train_encodersKIT as TK
+    records, tdir = _write_dataset(tmp_path, 4, 5)
+    labels = np.int32(records[:, 1])
+
+    def run(batched):
+        np.random.seed(21); torch.manual_seed(22)
+        ds = TK.samplePKBatches("Market", records, labels, 64, 32, tdir, 1, K=3)
+        ids = [2, 0, 3]
+        if batched:
+            imgs, lab, dist = ds.finish_batch(ds.plan_batch(ids, T.gpu_train_loader), T.gpu_train_loader, torch.device("cuda", 0))
+        else:
+            parts = [ds[i] for i in ids]
+            imgs, lab, dist = torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0), np.concatenate([p[2] for p in parts])
+        torch.cuda.synchronize()
+        return imgs.cpu(), lab, dist, np.random.rand(), torch.rand(1).item()          # the generators end in the same state too
+
+    TK.set_train_loader(None)
+    a, b = run(False), run(True)
+    assert a[0].shape == (18, 3, 64, 32) and torch.equal(a[0], b[0])
+    assert torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4]
+    assert (a[2].reshape(-1, 2)[:, 0] == 0).all() and (a[2].reshape(-1, 2)[:, 1] >= 1).all()
+
+
+def test_prefetch_overlaps_decode_with_gpu_work(T, tmp_path, monkeypatch):
+    """The PK loop of trainer.train with the batched loader: epoch wall time ~ max(host decode / threads, GPU), not their sum.  The decode is
+    made artificially slow and GIL-free (sleep) so that the statement does not depend on the box: 6 batches x 24 files x 20 ms = 2.9 s of
+    decode, 8 threads -> 0.36 s if parallel; the GPU step is stood in for by a 60 ms device spin per batch.  Sequential sum would be
+    > 3.2 s; overlapped ~ max(0.36, 0.36) + fill."""
+    import time
+    from daliid_amd import train_encodersKIT as TK
+    records, tdir = _write_dataset(tmp_path, 12, 4, hw=(64, 32))
+    labels = np.int32(records[:, 1])
+    monkeypatch.setenv("DALIID_DECODE_THREADS", "8")
+    monkeypatch.setattr(T, "_pool", None)
+    real = T._decode_one
+
+    def slow_decode(path):
+        time.sleep(0.02)
+        return real(path)
+    monkeypatch.setattr(T, "_decode_one", slow_decode)
+    ds = TK.samplePKBatches("Market", records, labels, 64, 32, tdir, 1, K=4)
+    loader = T.gpu_train_loader
+    dev = torch.device("cuda", 0)
+    spin = torch.zeros(1, device=dev)
+    m = torch.randn(4096, 4096, device=dev)
+    torch.mm(m, m); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        torch.mm(m, m)
+    e1.record(); torch.cuda.synchronize()
+    t_mm = e0.elapsed_time(e1) / 10 * 1e-3
+    reps = max(1, int(round(0.06 / t_mm)))
+
+    def gpu_step(imgs):                                  # ~60 ms of device time (calibrated above) that reads the batch
+        spin.add_(imgs.sum())
+        for _ in range(reps):
+            torch.mm(m, m)
+
+    def epoch(depth):
+        np.random.seed(1); torch.manual_seed(1)
+        batches = [[2 * b, 2 * b + 1] for b in range(6)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending, nxt = [], 0
+        for b in range(len(batches)):
+            while nxt < len(batches) and len(pending) < 1 + depth:
+                pending.append(ds.plan_batch(batches[nxt], loader)); nxt += 1
+            imgs, _, _ = ds.finish_batch(pending.pop(0), loader, dev)
+            gpu_step(imgs)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    epoch(2)                                             # warm-up (pool threads, allocator)
+    t_seq_decode = 6 * 16 * 0.02                         # 16 files per batch (2 ids x 4 x (clean, distorted)), one after the other
+    t_gpu = 6 * reps * t_mm
+    t = epoch(2)
+    print("prefetched epoch %.3f s (serial decode alone %.2f s, GPU alone %.2f s)" % (t, t_seq_decode, t_gpu))
+    assert t < 0.5 * (t_seq_decode + t_gpu)              # nowhere near the sum
+    assert t < 2.5 * max(t_seq_decode / 8, t_gpu) + 0.15
