@@ -289,6 +289,12 @@ __device__ __forceinline__ void pairdist_epilogue_lines(f32x4_t (&acc)[4][4], in
 // stage and stored as 512-byte contiguous rows (the stores cost 8 of the 11 us a tile spends outside its k-loop, found by
 // removing them; staged they cost 6, but the kernel reaches the 128-VGPR cap, spills 15 registers around the k-loop and the
 // k-step slows by 10 %).
+// Round 4: the tile now leaves through a private 2 KiB strip per consumer wave behind the ring (pairdist_epilogue_lines: whole 128-byte
+// lines per store, no spill: 123 VGPRs): 9.03 -> 8.72 ms (bf16 3.99 -> 3.62).  Measured and removed again: (a) 8 consumer + 4 producer waves
+// (3 waves per SIMD, 168 VGPRs): 8.93 against 8.91 ms, so four producers do feed the ring; (b) on that kernel, three of a tile's four query
+// columns kept in 48 registers and handed to the store path one (column, half) block every ktiles / 6 k-steps of the NEXT tile, so that
+// the stores run under its MFMAs: 9.41 ms (+5 %; bf16 3.64 against 3.51) -- stores issued inside the k-loop delay the LDS-DMA loads of the
+// same CU by more than the exposed burst costs; (c) start phases per XCD (blockIdx.x & 7) instead of per workgroup: 8.69-8.73 against 8.72.
 template <int NPROD>
 __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
                                                             const float* __restrict__ gsq, const float* __restrict__ qsq,
