@@ -456,11 +456,26 @@ def bench_epoch(args, world, rank):
     labels = (np.arange(N) % NID).astype(np.int32)
     records = np.array([["pool://%d" % i, str(labels[i]), str(i % 6), "person"] for i in range(N)])
 
+    def index_of(paths, turb):
+        idx = np.fromiter((int(p[7:]) for p in paths), dtype=np.int64, count=len(paths))
+        return (idx + 97 * int(turb[1])) % N if turb is not None else idx     # the distorted partner: another image of the pool
+
     def loader(paths, img_height, img_width, turb=None):
-        idx = torch.tensor([int(p[7:]) for p in paths], device=device)
-        if turb is not None:                                  # the distorted partner: another image of the pool
-            idx = (idx + 97 * int(turb[1])) % N
-        return pool[idx]
+        return pool[torch.from_numpy(index_of(paths, turb)).to(device)]
+
+    # the batched loader protocol of daliid_amd.transforms (plan -> submit -> finish): a PK batch is ONE gather from the pool instead of
+    # one per identity and distorted image, as the real-data loader's one resize + one augment launch per batch
+    class _Plan:
+        def __init__(self, idx):
+            self.files, self.idx = idx, idx
+
+        @staticmethod
+        def concat(plans, order=None):
+            idx = np.concatenate([p.idx for p in plans])
+            return _Plan(idx[np.asarray(order)] if order is not None else idx)
+    loader.plan = lambda paths, h, w, turb=None: _Plan(index_of(paths, turb))
+    loader.submit = lambda plan: plan
+    loader.finish = lambda plan, dev=None, side_stream=True: pool[torch.from_numpy(plan.idx).to(device)]
     getFeatures.set_image_loader(loader); T.set_train_loader(loader)
     try:
         online = Encoders._DataParallelShim(Encoders.ResNet50ReID(device=device, seed=12))

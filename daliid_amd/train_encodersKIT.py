@@ -117,7 +117,6 @@ class samplePKBatches:
         augmentation parameters, strengths, each distorted image's parameters), but the files are only LISTED -- in the final
         (clean, distorted, clean, distorted ...) order -- so that a whole PK batch is decoded on the pool and resized + augmented by one
         launch each (``plan_batch`` / ``finish_batch``).  -> (ImagePlan, labels tensor, distortion levels)"""
-        from .transforms import ImagePlan
         pid = self.labels_set[idx]
         names = self.images_names[self.labels == pid]
         sel = np.random.choice(names.shape[0], size=min(names.shape[0], self.K), replace=False)
@@ -130,15 +129,14 @@ class samplePKBatches:
                     for s, t in zip(sel, strengths)]
             k = len(sel)
             order = [j for i in range(k) for j in (i, k + i)]                          # clean_0, turb_0, clean_1, turb_1, ...
-            plan = ImagePlan.concat([clean] + turb, order)
+            plan = clean.concat([clean] + turb, order)                                 # (the plan type's own concat: transforms.ImagePlan.concat)
             dist = np.stack((np.zeros(k, dtype=np.int32), strengths.astype(np.int32)), 1).reshape(-1)
         return plan, torch.ones(len(plan.files)) * float(pid), dist
 
     def plan_batch(self, ids, loader):
         """Plans of the identities ``ids`` merged into one and submitted to the decode pool.  -> ticket for ``finish_batch``"""
-        from .transforms import ImagePlan
         parts = [self.plan(i, loader) for i in ids]
-        ticket = loader.submit(ImagePlan.concat([p[0] for p in parts]))
+        ticket = loader.submit(parts[0][0].concat([p[0] for p in parts]))
         return ticket, torch.cat([p[1] for p in parts], 0), np.concatenate([p[2] for p in parts])
 
     @staticmethod
