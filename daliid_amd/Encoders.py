@@ -255,13 +255,8 @@ class ResNet50ReID(nn.Module):
         _lib.check(_lib.lib().dali_resnet_backward(plan.h, _lib.stream_ptr(), _lib.ptr(d_emb, torch.float32, "d_emb"), stage, stage),
                    "dali_resnet_backward")
         if self.grad_stage_hook is not None:
-            self.join_grads()
             b, e = plan.stage_range(stage)
             self.grad_stage_hook(stage, b, e)
-
-    def join_grads(self):
-        """The stages run so far have their weight gradients complete on the current stream (dali_resnet_join_grads; the last stage joins itself)."""
-        _lib.check(_lib.lib().dali_resnet_join_grads(self._bwd_plan.h, _lib.stream_ptr()), "dali_resnet_join_grads")
 
     def attach_grads(self):
         """Point every parameter's .grad at its view of the flat gradient buffer (torch optimizers read .grad)."""

@@ -99,7 +99,6 @@ _SIGNATURES = {
     "dali_resnet_refresh_weights": [c_void_p, c_void_p],
     "dali_resnet_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "dali_resnet_backward": [c_void_p, c_void_p, c_void_p, c_int, c_int],
-    "dali_resnet_join_grads": [c_void_p, c_void_p],
     "dali_resnet_debug_tensor": [c_void_p, ctypes.c_char_p, c_void_p, c_void_p],
     "dali_vit_create": [c_void_p, c_void_p, ctypes.POINTER(c_void_p)],
     "dali_vit_destroy": [c_void_p],

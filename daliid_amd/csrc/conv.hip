@@ -1941,171 +1941,6 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
     }
 }
 
-// The same kernel, software-pipelined (round 3; NOT the default: it measured 5 % slower, see launch_igemm_wgrad).  Above, every wave requests its 3 DMA pieces, reads its 26 fragment halves, waits,
-// multiplies and meets the others at the barrier: per k-step 450 cycles of DMA issue + 550 of reads + 800 of MFMAs in sequence (diagnostic
-// stamps), both waves of a SIMD in the same part at the same time, the matrix pipe busy a third of the time (PMC mfma_busy 0.35).
-// Tried first and refuted: the two wave groups half a k-step apart ("ping-pong", one group reads while its SIMD partners multiply):
-// the read part (1300 cycles) is 1.6 x the multiply part, the multiplying group waits for the reading one, 195 us against 154.
-// Here a wave requests the NEXT k-step's fragments between the MFMAs of this one: tap k's two B reads right behind tap k's four MFMAs,
-// into the registers those MFMAs have just read (B needs no second register set), the three DMA pieces behind taps 2, 5 and 8, the eight
-// A reads behind the last tap.  The ring's bookkeeping is that of igemm_wgrad_p_kernel: at the barrier E_t that ends
-// iteration t every wave has waited for its own pieces of k-step t+2 and for its reads of k-step t+1; in iteration t >= 1 it requests
-// k-step t + NSTAGE - 1 into the stage k-step t - 1 left.
-template <int NSTAGE>
-__global__ __launch_bounds__(512) void igemm_wgrad3x3_p_kernel(WGradArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tiles = tiles_m * tiles_n;
-    const int work = tiles * a.splits, per_xcd = (work + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= work) return;
-    const int ks = item / tiles, tile = item - ks * tiles;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * 128, ci0 = tn * 64;
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
-    const bool m_active = m0 + wm * 64 < a.Cm;
-    const GatherGeom g = a.g;
-    const int W = g.Wout, H = g.Hout, Cin = g.Ck, lw = g.lw, lhw = g.lhw;
-    const int RW = 32 >> lw, HC = W + 2, HP = (RW + 2) * HC;
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
-    const long long x_bytes = (long long)g.img_pitch * 2 * (a.P >> lhw);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
-    // DMA pieces exactly as in igemm_wgrad3x3_kernel: piece 0 = this wave's 4 rows of the dY tile, pieces 1, 2 = 8 halo pixels each
-    const int r_in = lane >> 4, ps = lane & 15;
-    const int c16 = ((((ps >> 1) ^ wg_swz(4 * wave + r_in)) << 1) | (ps & 1));
-    const int am = m0 + c16 * 8;
-    const bool a_ok = am < a.Cm;
-    int hb_hr[2], hb_off[2];
-    bool hb_ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int hp = 8 * (wave + 8 * i) + (lane >> 3);
-        const int lc = (lane & 7) ^ (halo_swz(hp) << 1);
-        const int hr = hp / HC, hc = hp - hr * HC;
-        hb_hr[i] = hr;
-        hb_ok[i] = hp < HP && (unsigned)(hc - 1) < (unsigned)W && ci0 + lc * 8 < Cin;
-        hb_off[i] = ((hc - 1) * Cin + ci0 + lc * 8) * 2;
-    }
-    const int p_begin = ks * a.pix_per_split;
-    const int p_end = min(a.P, p_begin + a.pix_per_split);
-    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
-    auto issue_piece = [&](int kt, int piece) {          // piece 0: dY rows, 1 / 2: halo pixels
-        uint16_t* sa = smem + (kt % NSTAGE) * W3_STAGE;
-        const int p0 = p_begin + kt * 32;
-        if (piece == 0) {
-            const int p = p0 + 4 * wave + r_in;
-            const uint32_t oa = (p < p_end && a_ok) ? (uint32_t)(p * a.Cm + am) * 2u : DMA_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)(sa + wave * 512), 16, oa, 0, 0, 0);
-        } else {
-            const int i = piece - 1;
-            const int n = p0 >> lhw, h_base = (p0 & ((1 << lhw) - 1)) >> lw;
-            const int h = h_base - 1 + hb_hr[i];
-            const bool ok = hb_ok[i] && (unsigned)h < (unsigned)H && p0 < p_end;
-            const uint32_t ob = ok ? (uint32_t)((int)((long long)n * g.img_pitch * 2) + h * (W * Cin * 2) + hb_off[i]) : DMA_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sa + W3_A_ELEMS + (wave + 8 * i) * 512), 16, ob, 0, 0, 0);
-        }
-    };
-    f32x4_t acc[9][4];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int hrow_base = ((8 * gq) >> lw) * HC + ((8 * gq) & (W - 1)) + q;
-    int boff0[9], boff1[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) {
-            const int row0 = hrow_base + r * HC + s2, row1 = row0 + 4;
-            boff0[r * 3 + s2] = row0 * 64 + ((wn ^ halo_swz(row0)) << 4) + 4 * pp;
-            boff1[r * 3 + s2] = row1 * 64 + ((wn ^ halo_swz(row1)) << 4) + 4 * pp;
-        }
-    static_assert(NSTAGE >= 4 && NSTAGE <= 6, "ring depth");
-    constexpr int LEAD = NSTAGE - 3;                     // k-steps (3 pieces each) that may stay in flight at the barrier
-    auto wait_keep = [&](int n) {
-        if (n <= 0) dma_wait<0>();
-        else if (n == 1) dma_wait<3>();
-        else if (n == 2) dma_wait<6>();
-        else dma_wait<9>();
-    };
-    TrPair ra[4], rb[9];
-    if (ksteps > 0) {
-        int issued = 0;
-        for (; issued < NSTAGE && issued < ksteps; ++issued) { issue_piece(issued, 0); issue_piece(issued, 1); issue_piece(issued, 2); }
-        { const int keep = issued - 2; wait_keep(keep < 0 ? 0 : (keep > LEAD ? LEAD : keep)); }      // k-steps 0 and 1 have landed
-        __builtin_amdgcn_s_barrier();                              // P0
-        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
-        if (m_active) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = tr_frag_raw(smem, wm * 4 + i, lane);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) rb[k] = TrPair{ds_read_tr_raw(smem + W3_A_ELEMS + boff0[k]), ds_read_tr_raw(smem + W3_A_ELEMS + boff1[k])};
-            tr_settle<0>(ra[0], ra[1], ra[2], ra[3]);
-            tr_settle<0>(rb[0], rb[1], rb[2], rb[3]);
-            tr_settle<0>(rb[4], rb[5], rb[6], rb[7]);
-            tr_settle_all(rb[8]);
-        }
-        int st = 1 % NSTAGE;                                       // stage of k-step t + 1
-        for (int t = 0; t < ksteps; ++t) {
-            const bool rd = t + 1 < ksteps, dma = t >= 1 && issued < ksteps;
-            const uint16_t* sa = smem + st * W3_STAGE;
-            const uint16_t* sb = sa + W3_A_ELEMS;
-            // multiplies of k-step t; behind tap k's MFMAs the two B requests of k-step t + 1 into the registers they have just read; the
-            // DMA pieces of k-step `issued` behind taps 2, 5 and 8; the A requests last (A is read by every tap: a second A set did not
-            // fit the 256 registers, so its eight reads return in the open, ~170 cycles of a ~1300-cycle k-step)
-            if (m_active) {
-                bf16x8_t fa[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = tr_join(ra[i]);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const bf16x8_t fb = tr_join(rb[k]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[k][i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);             // the requests below stay behind this tap's MFMAs (they overwrite rb[k])
-                    if (rd) rb[k] = TrPair{ds_read_tr_raw(sb + boff0[k]), ds_read_tr_raw(sb + boff1[k])};
-                    if (dma && (k == 2 || k == 5 || k == 8)) issue_piece(issued, k / 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (rd) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ra[i] = tr_frag_raw(sa, wm * 4 + i, lane);
-                    tr_settle<0>(ra[0], ra[1], ra[2], ra[3]);
-                    tr_settle<0>(rb[0], rb[1], rb[2], rb[3]);
-                    tr_settle<0>(rb[4], rb[5], rb[6], rb[7]);
-                    tr_settle_all(rb[8]);
-                }
-            } else if (dma) { issue_piece(issued, 0); issue_piece(issued, 1); issue_piece(issued, 2); }
-            if (dma) ++issued;
-            const int keep = issued - (t + 3);                     // k-step t + 2 has landed at E_t
-            wait_keep(keep < 0 ? 0 : (keep > LEAD ? LEAD : keep));
-            __builtin_amdgcn_s_barrier();                          // E_t
-            st = st + 1 == NSTAGE ? 0 : st + 1;
-        }
-    }
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
-    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
-    if (m_active) {                                      // one row pointer per (i, r), the nine taps Cin columns apart
-        float* row = slab + (size_t)(m0 + wm * 64 + (lane >> 4) * 4) * a.Ntot + ci0 + wn * 16 + (lane & 15);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                float* p = row + (size_t)(i * 16 + rr) * a.Ntot;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) p[t * Cin] = acc[t][i][rr];
-            }
-    }
-    if (a.stamps) {
-        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
-    }
-}
-
 // wgrad, wave-grid variant: WM x WN waves of 64 x 64 sub-tiles; the (64*WM) x (64*WN) block tile is held as (TM+TN)/128
 // swizzled [32 px][128 ch] LDS images per stage (same image / tr-read scheme as above), NSTAGE-deep ring.
 template <int WM, int WN, int NSTAGE, bool COLSUM = false>
@@ -2271,189 +2106,9 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void igemm_wgrad_wg_kernel(WGradAr
     }
 }
 
-// Wave-specialised variant of igemm_wgrad_wg_kernel: WM x WN consumer waves (transposing fragment reads + MFMAs + the slab
-// store) and NP producer waves (pixel decode, gather arithmetic, DMA pieces), see igemm_conv_k64s_kernel.  One workgroup per
-// CU (16 waves at <= 128 VGPRs), so the ring can be NSTAGE = 4 deep (3 k-steps in flight).
-template <int WM, int WN, int NP, int NSTAGE, bool COLSUM = false>
-__global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_wgs_kernel(WGradArgs a, int tiles_m, int tiles_n) {
-    constexpr int TM = 64 * WM, TN = 64 * WN, NC = WM * WN;
-    constexpr int IMG = 32 * 128, NIMG_A = TM / 128, NIMG = (TM + TN) / 128;
-    constexpr int NBLK = NIMG * 8 / NP;                 // 1 KiB DMA pieces per producer per k-step
-    constexpr int AHEAD = NSTAGE - 1;
-    static_assert((NIMG * 8) % NP == 0 && NP % 8 == 0 && TM % 128 == 0 && TN % 128 == 0, "unsupported wave grid");
-    static_assert(AHEAD >= 1 && AHEAD <= 4, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles = tiles_m * tiles_n;
-    const int work = tiles * a.splits, per_xcd = (work + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= work) return;
-    const int ks = item / tiles, tile = item - ks * tiles;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * TM, n0 = tn * TN;
-    const GatherGeom g = a.g;
-    const int p_begin = ks * a.pix_per_split;
-    const int p_end = min(a.P, p_begin + a.pix_per_split);
-    const int ksteps = (p_end > p_begin) ? (p_end - p_begin + 31) >> 5 : 0;
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
-    if (wave >= NC) {
-        // ---------------- producers ----------------
-        if (ksteps == 0) return;
-        const int pw = wave - NC;
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.dY), 0, a.P * a.Cm * 2, 0x00020000);
-        const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
-        // this producer's pieces: q = pw + NP*i -> image q>>3, piece q&7 (rows 4*(q&7) + lane>>4); (q&7) is the same for every i
-        const int r_in = lane >> 4, ps = lane & 15;
-        const int blk = pw & 7;
-        const int c16 = ((((ps >> 1) ^ wg_swz(4 * blk + r_in)) << 1) | (ps & 1));
-        bool is_a[NBLK], col_ok[NBLK];
-        int col[NBLK], tap_r[NBLK], tap_s[NBLK], img_of[NBLK];
-#pragma unroll
-        for (int i = 0; i < NBLK; ++i) {
-            const int q = pw + NP * i, img = q >> 3;
-            img_of[i] = img;
-            is_a[i] = img < NIMG_A;
-            if (is_a[i]) {
-                col[i] = m0 + img * 128 + c16 * 8;
-                col_ok[i] = col[i] < a.Cm;
-                tap_r[i] = tap_s[i] = 0;
-            } else {
-                const int bn = n0 + (img - NIMG_A) * 128 + c16 * 8;
-                col_ok[i] = bn < a.Ntot;
-                const int tap = col_ok[i] ? bn / g.Ck : 0;
-                col[i] = bn - tap * g.Ck;
-                tap_r[i] = tap / g.S; tap_s[i] = tap - tap_r[i] * g.S;
-            }
-        }
-        auto issue = [&](int kt, int stage) {
-            uint16_t* base = smem + stage * NIMG * IMG;
-            const int p = p_begin + kt * 32 + 4 * blk + r_in;
-            int n = 0, ho = 0, wo = 0;
-            const bool pok = p < p_end;
-            if (pok) decode_pixel(g, p, n, ho, wo);
-            const int pix_base = (int)((long long)n * g.img_pitch);
-#pragma unroll
-            for (int i = 0; i < NBLK; ++i) {
-                uint32_t off = DMA_OOB;
-                if (pok && col_ok[i]) {
-                    if (is_a[i]) off = (uint32_t)(p * a.Cm + col[i]) * 2u;
-                    else {
-                        const int hi = ho * g.stride - g.pad + tap_r[i], wi = wo * g.stride - g.pad + tap_s[i];
-                        if ((unsigned)hi < (unsigned)g.Hin && (unsigned)wi < (unsigned)g.Win)
-                            off = (uint32_t)(pix_base + hi * g.row_pitch + wi * g.pix_pitch + col[i]) * 2u;
-                    }
-                }
-                uint16_t* dst = base + img_of[i] * IMG + blk * 512;
-                if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_void_ptr)dst, 16, off, 0, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)dst, 16, off, 0, 0, 0);
-            }
-        };
-        auto wait_all_but = [&](int tiles_in_flight) {            // all but the youngest `tiles_in_flight` k-steps have landed
-            if (tiles_in_flight <= 0) dma_wait<0>();
-            else if (tiles_in_flight == 1) dma_wait<NBLK>();
-            else if (tiles_in_flight == 2) dma_wait<2 * NBLK>();
-            else dma_wait<3 * NBLK>();
-        };
-        int issued = 0;
-        for (; issued < AHEAD && issued < ksteps; ++issued) issue(issued, issued);
-        wait_all_but(issued - 1);
-        __builtin_amdgcn_s_barrier();                              // k-step 0 visible
-        int st_fill = AHEAD % NSTAGE;
-        for (int kt = 0; kt < ksteps; ++kt) {
-            // the stage of k-step kt+AHEAD was last read in iteration kt-1, which every consumer left through the previous barrier
-            if (kt + AHEAD < ksteps) issue(kt + AHEAD, st_fill);
-            const int left = ksteps - 1 - kt;
-            wait_all_but((left < AHEAD ? left : AHEAD) - 1);       // k-step kt+1 has landed
-            __builtin_amdgcn_s_barrier();
-            st_fill = (st_fill == NSTAGE - 1) ? 0 : st_fill + 1;
-        }
-        return;
-    }
-    // ---------------- consumers ----------------
-    const int wm = wave / WN, wn = wave % WN;
-    // COLSUM: column sums of dY over this split's pixels ride on the GEMM as one more MFMA per A fragment against an all-ones operand
-    // (see igemm_wgrad_dma_kernel), in the wn-0 waves, whose A fragments cover each channel of the m tile exactly once.  All n tiles of an
-    // (m tile, split) see the same dY: they share the k-steps round-robin (n tile tn takes kt = tn mod tiles_n) and leave tiles_n partial
-    // rows -- with the n-tile-0 workgroups alone doing it the launch waited for their 25 % longer main loops (6.6 against 5.0 ms per step).
-    // One accumulator for the 4 A fragments: fragment i is multiplied by an operand that is all ones in result columns 4i .. 4i+3 and zero
-    // elsewhere, so column 4i of the 16 x 16 result carries fragment i's row sums (16 accumulator registers for the four sums spilled
-    // inside the main loop of the 128-register kernel).
-    const bool do_cs = COLSUM && wn == 0;
-    int cs_turn = tn;                                    // k-steps until this workgroup's next turn
-    f32x4_t cs = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    typedef unsigned sel_vec_t __attribute__((ext_vector_type(4)));
-    const int cs_col = (lane & 15) >> 2;                 // the fragment whose sums this lane's result column carries
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (ksteps > 0) {
-        __builtin_amdgcn_s_barrier();
-        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
-        int st_cur = 0;
-        for (int kt = 0; kt < ksteps; ++kt) {
-            const uint16_t* sa = smem + st_cur * NIMG * IMG + (wm >> 1) * IMG;
-            const uint16_t* sb = smem + st_cur * NIMG * IMG + (NIMG_A + (wn >> 1)) * IMG;
-            bf16x8_t fa[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = tr_frag(sa, (wm & 1) * 4 + i, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8_t fb = tr_frag(sb, (wn & 1) * 4 + j, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
-            }
-            if constexpr (COLSUM) if (do_cs) {
-                if (cs_turn == 0) {
-                    int opaque;                          // the select operands are built here, per use: hoisted out of the loop they cost 16 registers
-                    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const unsigned w = (cs_col + opaque == i) ? 0x3F803F80u : 0u;        // bf16 (1, 1) or (0, 0)
-                        cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], __builtin_bit_cast(bf16x8_t, sel_vec_t{w, w, w, w}), cs, 0, 0, 0);
-                    }
-                    cs_turn = tiles_n;
-                }
-                --cs_turn;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of this stage are complete before it can be refilled
-            __builtin_amdgcn_s_barrier();
-            st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
-        }
-    }
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
-    float* slab = a.partial + (size_t)ks * a.Cm * a.Ntot;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
-                if (m < a.Cm && n < a.Ntot) slab[(size_t)m * a.Ntot + n] = acc[i][j][rr];
-            }
-        }
-    if constexpr (COLSUM) if (do_cs && (lane & 3) == 0) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int m = m0 + wm * 64 + cs_col * 16 + (lane >> 4) * 4 + rr;
-            if (m < a.Cm) a.colsum[((size_t)ks * tiles_n + tn) * a.Cm + m] = cs[rr];
-        }
-    }
-    if (a.stamps) {
-        const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) { a.stamps[(size_t)blockIdx.x * 12 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 12 + 4] = t_issued; }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Pipelined weight gradient (round 3).  Same GEMM, LDS images ([32 px][128 ch], swizzled, transposing fragment reads) and split-K slabs
-// as igemm_wgrad_wgs_kernel; what changes is WHEN a consumer wave reads its fragments.  In the kernels above a wave reads the 16
+// as igemm_wgrad_wg_kernel; what changes is WHEN a consumer wave reads its fragments.  In the kernels above a wave reads the 16
 // fragment halves of k-step t, waits for them, multiplies, and meets the other waves at the barrier: the LDS reads and the MFMAs of a
 // wave never overlap, and since every wave of the workgroup leaves the same barrier together, the two waves of a SIMD read together and
 // multiply together as well (stamps: 0.55 us per 32-pixel k-step of a 128 x 256 tile for 0.21 us of MFMA work).  Here the fragments of
@@ -2659,7 +2314,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_wgrad_p_kernel(WGra
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
     };
-    // COLSUM (bias gradients of the linear layers): column sums of dY over this split's pixels, as in igemm_wgrad_wgs_kernel: one more MFMA per A fragment
+    // COLSUM (bias gradients of the linear layers): column sums of dY over this split's pixels, as in igemm_wgrad_wg_kernel: one more MFMA per A fragment
     // against a column-select operand (fragment i' of a wave's share lands in result column 4 i'), the n tiles of an (m tile, split) taking the k-steps
     // in turn.  The WN waves of a consumer row hold the same FM A fragments: each sums FM / WN of them (all on the wn-0 wave, 8 extra MFMAs in its turn
     // steps while the other three waited at the barrier: 4.76 ms for the ViT's 48 weight gradients against 4.67 shared).
@@ -2836,12 +2491,9 @@ static int conv_k64_mode() { return DALI_ENV_INT("DALI_CONV_K64", 2); }
 // ViT's 25216 x 768 outputs are 297 tiles of 256 x 256 = 2 rounds for 1.16 rounds of work (measured: 145 us, 144 of 256 CUs busy on
 // average) but 237 tiles of 256 x 320 = one round of 1.25 x the work.  Taken where rounds x tile size says so by a margin; only for
 // launches without BatchNorm statistics (their slab layout is fixed by igemm_conv_stat_tiles before the launch is known).
-// DALI_CONV_320=0 switches it off, DALI_CONV_320_MINK sets the shortest K it is used for (A/B aids).
+// (K >= 512; K = 768: 28.9 -> 28.0..28.6 ms per ViT step against a limit of 1024)
 static bool conv_prefers_320(int Cm, int P, int K) {
-    static int on = -1, mink = -1;
-    if (on < 0) { const char* e = getenv("DALI_CONV_320"); on = e ? atoi(e) : 1; }
-    if (mink < 0) { const char* e = getenv("DALI_CONV_320_MINK"); mink = e ? atoi(e) : 512; }      // (K = 768: 28.9 -> 28.0..28.6 ms per ViT step against 1024)
-    if (!on || Cm < 512 || P < 16384 || K < mink) return false;
+    if (Cm < 512 || P < 16384 || K < 512) return false;
     const long long tm = (Cm + 255) / 256, t256 = tm * ((P + 255) / 256), t320 = tm * ((P + 319) / 320);
     const double c256 = (double)((t256 + 255) / 256), c320 = 1.25 * (double)((t320 + 255) / 256);
     return c320 < 0.85 * c256;
@@ -2898,7 +2550,6 @@ struct ProfScope {
 // Host-side launchers shared with the net plan (resnet_plan.hip).
 static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a);
 static bool narrow_cm(int Cm) { return Cm <= 64; }
-static bool dgrad_substage() { return DALI_ENV_INT("DALI_DGRAD_SUBSTAGE", 1) != 0; }    // 0: parity classes through the general epilogue again (A/B aid)
 static unsigned long long* g_conv_stamps = nullptr;      // diagnostic only, see dali_debug_set_conv_stamps
 
 // Stride-2 data gradients are split by output parity: output position (2h'+ph, 2w'+pw) only receives the taps
@@ -2912,10 +2563,9 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     GatherGeom& g = args.g;
     g.sub = 0; g.oph = g.opw = 0; g.Hfull = g.Hout; g.Wfull = g.Wout;
     g.r0 = 0; g.rstep = 1; g.nr = g.R; g.s0 = 0; g.sstep = 1; g.ns = g.S;
-    static const bool no_split = getenv("DALI_DGRAD_NOSPLIT") != nullptr;
     const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
     const bool dma_ok = !a.in_scale && x_bytes < 0x7ff00000ll && (long long)a.Cm * g.R * g.S * g.Ck * 2 < 0x7ff00000ll;
-    if (g.mode == 1 && g.stride == 2 && dma_ok && !a.stats && !no_split && (g.Hout % 2) == 0 && (g.Wout % 2) == 0 &&
+    if (g.mode == 1 && g.stride == 2 && dma_ok && !a.stats && (g.Hout % 2) == 0 && (g.Wout % 2) == 0 &&
         ilog2_exact(g.Wout / 2) >= 0 && ilog2_exact((g.Hout / 2) * (g.Wout / 2)) >= 0) {
         int nr[2], ns[2];
         for (int ph = 0; ph < 2; ++ph) {
@@ -2925,8 +2575,8 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
         }
         const bool all_have = nr[0] && nr[1] && ns[0] && ns[1];
         // every class has taps (3x3): ONE launch, the workgroups of the four classes interleaved (parity_block); the four separate launches
-        // of a quarter of the pixels each ran one after the other with a short-K tail each.  DALI_DGRAD_MERGE=0: separate launches (A/B aid)
-        if (all_have && !narrow_cm(a.Cm) && (a.Cm & 7) == 0 && DALI_ENV_INT("DALI_DGRAD_MERGE", 1) && DALI_ENV_INT("DALI_CONV_CFG", -1) < 0 && dgrad_substage()) {
+        // of a quarter of the pixels each ran one after the other with a short-K tail each (layer2 / layer3 conv2: 96 -> 72 us, 85 -> 53 us)
+        if (all_have && !narrow_cm(a.Cm) && (a.Cm & 7) == 0 && conv_cfg_override() < 0) {
             IGemmArgs s = args;
             s.g.sub = 2; s.g.oph = s.g.opw = 0; s.g.Hfull = g.Hout; s.g.Wfull = g.Wout;
             s.g.Hout = g.Hout / 2; s.g.Wout = g.Wout / 2; s.P = a.P / 4;
@@ -2984,9 +2634,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const bool lin = a.act != 0 || a.O2 != nullptr || a.dact_pre != nullptr || a.row_scale != nullptr;      // linear-layer epilogue extras: the LIN kernel instantiations
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
     const int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
-    static int k64_min_k = -1;                         // DALI_CONV_K64_MINK (A/B aid)
-    if (k64_min_k < 0) { const char* e = getenv("DALI_CONV_K64_MINK"); k64_min_k = e ? atoi(e) : 1024; }
-    if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !((K >= k64_min_k && (cfg == CONV_256x256 || cfg == CONV_128x256)) || (K >= 768 && cfg == CONV_256x256))) k64 = 0;
+    if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !((K >= 1024 && (cfg == CONV_256x256 || cfg == CONV_128x256)) || (K >= 768 && cfg == CONV_256x256))) k64 = 0;
     // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
     // instantiations compile none of it (code that is never executed still cost their register allocation 0.4-0.8 ms per step)
     const bool fused = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;
@@ -3010,7 +2658,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
             hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         }
-    } else if (a.g.sub && !in_bn && dma_ok && !narrow && !lin && (a.Cm & 7) == 0 && conv_cfg_override() < 0 && dgrad_substage()) {
+    } else if (a.g.sub && !in_bn && dma_ok && !narrow && !lin && (a.Cm & 7) == 0 && conv_cfg_override() < 0) {
         // a parity class of a stride-2 data gradient: the staged store with scattered pixel rows (EPI = 4)
         DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 256) * 64 * 2 * 2));
@@ -3069,7 +2717,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 2, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), 256 * 64 * 2 * 2, st, args, tiles_m, tiles_n);
     } else if (narrow_k64 == 2 && a.Cm == 64 && a.g.Ck == 64 && a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && !a.g.sub && !lin &&
                (a.g.Wout == 16 || a.g.Wout == 32) && args.g.lhw >= 8 && a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == 64 &&
-               a.g.row_pitch == a.g.Win * 64 && a.g.img_pitch == (long long)a.g.Hin * a.g.Win * 64 && a.P % 256 == 0 && DALI_ENV_INT("DALI_CONV_HALO64", 1)) {
+               a.g.row_pitch == a.g.Win * 64 && a.g.img_pitch == (long long)a.g.Hin * a.g.Win * 64 && a.P % 256 == 0) {
         // layer1's 3x3 (64 -> 64): the halo patch of a 256-pixel tile fetched once, taps read it at shifted pixels (igemm_conv_halo64_kernel)
         const int lds = (3 * 64 * 64 + HALO64_PX * 64) * 2;
         DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_halo64_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
@@ -3081,14 +2729,9 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         // workgroup per CU: 122 / 118)
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
         const int lds = (64 + 256) * 64 * 2 * 2;
-        static int narrow_np = -1;                         // DALI_NARROW_NP (A/B aid): producer waves of the narrow k-tile-64 kernel
-        if (narrow_np < 0) { const char* e = getenv("DALI_NARROW_NP"); narrow_np = e ? atoi(e) : 4; }
-        DALI_ONCE_PER_DEVICE({
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        });
-        if (narrow_np == 8) hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 8, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(768), lds, st, args, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        // (8 producer waves instead of 4: 74 -> 78 us; the L2 -> LDS feed, 9 taps per pixel, bounds it, not the issue of the DMA pieces)
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<1, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+        hipLaunchKernelGGL((igemm_conv_k64s_kernel<1, 4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
     } else if (narrow) {
         using Cfg = GemmCfg<64, 256, 1, 1, 1>;
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
@@ -3136,35 +2779,20 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
 // 1 = 256 x 256 / 16 waves, 2 = 128 x 256 / 8 waves.  The wider tiles cut the L2 -> LDS operand bytes per FLOP and win
 // on the 1x1 layers with a long pixel (K) dimension; on 3x3 layers (each 128-column group of N is one tap's gather)
 // and on the ViT linears (25 k rows: the split-K slabs double) they lose.
-// DALI_WGRAD_SPEC=0 (A/B aid): the unspecialised 128 x 256 weight-gradient kernel, two workgroups per CU
-static int wgrad_spec_env() { return DALI_ENV_INT("DALI_WGRAD_SPEC", -1); }
-// the 128 x 256 weight-gradient kernel: wave-specialised (one workgroup per CU) when the problem has few output tiles, the plain
-// 8-wave kernel (two workgroups per CU = 16 MFMA waves) when the tiles alone nearly fill the chip.  DALI_WGRAD_SPEC=0/1 forces one
-// form, DALI_WGRAD_SPEC_TILES moves the threshold (A/B aids).
-static bool wgrad_spec(int Cm, int Ntot) {
-    const int ov = wgrad_spec_env();
-    if (ov >= 0) return ov != 0;
-    // (40 until the pipelined kernel carried the column sums: with them it wins at the ViT's 54 / 72 tiles too -- 48 weight gradients 5.46 -> 4.67 ms --
-    //  and at layer4's downsample, 64 tiles: 162 -> 125 us)
-    return ((Cm + 127) / 128) * ((Ntot + 255) / 256) <= DALI_ENV_INT("DALI_WGRAD_SPEC_TILES", 100);
-}
-// DALI_WGRAD_P (A/B aid): 0 = the round-2 kernels, 1 (default) = igemm_wgrad_p_kernel with 4 consumers of 128 x 64 + 4 producers, 2 = with 8 consumers of
-// 64 x 64 + 4 producers, 3 = 8 consumers + 8 producers
-static int wgrad_p_mode() { return DALI_ENV_INT("DALI_WGRAD_P", 1); }
+// the 128 x 256 weight-gradient kernel: the pipelined wave-specialised form (igemm_wgrad_p_kernel, one workgroup per CU) when the problem has
+// few output tiles, the plain 8-wave kernel (two workgroups per CU = 16 MFMA waves) when the tiles alone nearly fill the chip.
+// (The limit was 40 tiles until the pipelined kernel carried the column sums: with them it wins at the ViT's 54 / 72 tiles too -- 48 weight
+//  gradients 5.46 -> 4.67 ms -- and at layer4's downsample, 64 tiles: 162 -> 125 us.)
+static bool wgrad_spec(int Cm, int Ntot) { return ((Cm + 127) / 128) * ((Ntot + 255) / 256) <= 100; }
 int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P, int halo_w) {
     const int ov = DALI_ENV_INT("DALI_WGRAD_CFG", -1);
     // 3 = 3x3 halo kernel (128 co x 64 ci x 9 taps per block)
     if (ov != 0 && taps == 9 && (halo_w == 8 || halo_w == 16 || halo_w == 32) && Cm % 64 == 0 && (Ntot / 9) % 64 == 0 && P % 32 == 0) return 3;
     if (ov == 2) return (Ntot >= 256) ? 2 : 0;
     if (ov >= 0) return (ov == 1 && Cm >= 256 && Ntot >= 256) ? 1 : 0;
-    static int minp = -1;                               // DALI_WGRAD_CFG2_MINP (A/B aid)
-    if (minp < 0) { const char* e = getenv("DALI_WGRAD_CFG2_MINP"); minp = e ? atoi(e) : 16384; }
-    return (taps == 1 && Ntot >= 256 && P >= minp) ? 2 : 0;       // incl. the ViT linears (P = 25216)
+    return (taps == 1 && Ntot >= 256 && P >= 16384) ? 2 : 0;      // incl. the ViT linears (P = 25216)
 }
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps, int halo_w) {
-    static int target_override = -2;
-    if (target_override == -2) { const char* e = getenv("DALI_WGRAD_TARGET"); target_override = e ? atoi(e) : -1; }
-    if (target_override > 0) target_blocks = target_override;
     const int cfg = wgrad_pick_cfg(Cm, Ntot, taps, P, halo_w);
     const int TMc = cfg == 1 ? 256 : 128, TNc = cfg == 0 ? 128 : (cfg == 3 ? 9 * 64 : 256);
     if (cfg == 1 || cfg == 3) target_blocks = 256;  // one 16-wave / 8-wave block per CU
@@ -3178,11 +2806,9 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
     // 768 x 3072 weight: 72 tiles x 8 = 576 for 512 places; 768 x 768: 18 x 15 = 270 for 256), so take the split with the least
     // rounds(tiles * s) / s instead, the smallest on a tie (fewer slabs).  Power-of-two tile counts (ResNet) keep the split they had.
     {
-        static int quant = -1;                       // DALI_WGRAD_QUANT=0: the old rule (A/B aid)
-        if (quant < 0) { const char* e = getenv("DALI_WGRAD_QUANT"); quant = e ? atoi(e) : 1; }
         int best = sp;
         double best_cost = (double)((tiles * sp + target_blocks - 1) / target_blocks) / sp;
-        for (int c = sp - 1; quant && c >= 1 && c >= sp / 2; --c) {
+        for (int c = sp - 1; c >= 1 && c >= sp / 2; --c) {
             const double cost = (double)((tiles * c + target_blocks - 1) / target_blocks) / c;
             if (cost <= best_cost + 1e-12) { best = c; best_cost = cost; }
         }
@@ -3220,20 +2846,12 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
         const int tm3 = (a.Cm + 127) / 128, tn3 = a.g.Ck / 64;
         const int lds = 3 * W3_STAGE * 2;            // 3 stages x 24 KiB (4 and 5 measured the same, before and after the inline-asm reads: the
                                                      // k-step is bound by its 26 transposing reads + 36 MFMAs per wave, two waves per SIMD)
-        DALI_ONCE_PER_DEVICE({
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_p_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 5));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_p_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 6));
-        });
-        // DALI_WGRAD3X3_P: 0 (default) = the round-2 kernel, 5 / 6 = the software-pipelined kernel with that ring depth (A/B aid).  Measured,
-        // interleaved in one process: layer4 conv2 152 us (round 2) against 161 (pipelined) and 195 (ping-pong); layer2 / layer3 66 against 68.
-        // PMC on the round-2 kernel at the layer4 shape: matrix pipe busy 45 % of the SIMD cycles, LDS active 23 % (28 % of that bank
-        // conflicts), waves parked at s_waitcnt / barriers 26 % of their cycles: neither the issue order nor the LDS bounds it.
-        const int pm = DALI_ENV_INT("DALI_WGRAD3X3_P", 0);
+        DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+        // (measured and removed, round 3: the same kernel software-pipelined -- layer4 conv2 161 us against 152 -- and as two wave groups half a
+        //  k-step apart, 195 us.  PMC on this kernel at the layer4 shape: matrix pipe busy 45 % of the SIMD cycles, LDS active 23 % (28 % of that bank
+        //  conflicts), waves parked at s_waitcnt / barriers 26 % of their cycles: neither the issue order nor the LDS bounds it.)
         const dim3 grid3(((tm3 * tn3 * a.splits + 7) / 8) * 8);
-        if (pm == 5) hipLaunchKernelGGL(igemm_wgrad3x3_p_kernel<5>, grid3, dim3(512), lds / 3 * 5, st, args, tm3, tn3);
-        else if (pm) hipLaunchKernelGGL(igemm_wgrad3x3_p_kernel<6>, grid3, dim3(512), lds / 3 * 6, st, args, tm3, tn3);
-        else hipLaunchKernelGGL(igemm_wgrad3x3_kernel<3>, grid3, dim3(512), lds, st, args, tm3, tn3);
+        hipLaunchKernelGGL(igemm_wgrad3x3_kernel<3>, grid3, dim3(512), lds, st, args, tm3, tn3);
     } else if (!a.in_scale && dma_ok && wcfg == 1) {
         const int tm2 = (a.Cm + 255) / 256, tn2 = (a.Ntot + 255) / 256;
         const int lds = 4 * 4 * 32 * 128 * 2;       // 4 stages x 4 images x 8 KiB
@@ -3244,18 +2862,13 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
         const int lds = 3 * 3 * 32 * 128 * 2;       // 3 stages x 3 images x 8 KiB
         DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wg_kernel<2, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_wgs_kernel<2, 4, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds / 3 * 4));
         });
         const dim3 grid2(((tm2 * tn2 * a.splits + 7) / 8) * 8);
-        const int pmode = wgrad_p_mode();
-        const bool p_cs = DALI_ENV_INT("DALI_WGRAD_P_CS", 1) != 0;          // A/B aid: 0 = column sums on the round-2 kernels
-        if (pmode && (!a.colsum || p_cs) && wgrad_spec(a.Cm, a.Ntot)) {   // (where the specialised kernel ran: few output tiles, one workgroup per CU)
+        if (wgrad_spec(a.Cm, a.Ntot)) {                 // few output tiles: the pipelined wave-specialised kernel, one workgroup per CU
             constexpr int lds_p = 6 * 3 * 32 * 128 * 2;   // 6 stages x 3 images x 8 KiB
             DALI_ONCE_PER_DEVICE({
                 DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
-                DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 4, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
                 DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
                 DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
                 DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
@@ -3266,15 +2879,10 @@ int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accum
             const bool flat = gg.R == 1 && gg.S == 1 && gg.stride == 1 && gg.pad == 0 && gg.pix_pitch == gg.Ck && gg.row_pitch == gg.Win * gg.Ck &&
                               gg.img_pitch == (long long)gg.Hin * gg.Win * gg.Ck && gg.Hin == gg.Hout && gg.Win == gg.Wout;
             if (a.colsum) {                                     // bias gradients of the linear layers / the Gram scheme's column sums ride on the GEMM
-                if (pmode == 3 || !flat) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6, true>), grid2, dim3(1024), lds_p, st, args, tm2, tn2);
+                if (!flat) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6, true>), grid2, dim3(1024), lds_p, st, args, tm2, tn2);
                 else hipLaunchKernelGGL((igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6, true>), grid2, dim3(512), lds_p, st, args, tm2, tn2);
-            } else
-            if (pmode == 3 || (pmode == 1 && !flat)) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6>), grid2, dim3(1024), lds_p, st, args, tm2, tn2);
-            else if (pmode == 2) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 4, 6>), grid2, dim3(768), lds_p, st, args, tm2, tn2);
+            } else if (!flat) hipLaunchKernelGGL((igemm_wgrad_p_kernel<2, 4, 4, 4, 8, 6>), grid2, dim3(1024), lds_p, st, args, tm2, tn2);
             else hipLaunchKernelGGL((igemm_wgrad_p_kernel<1, 4, 8, 4, 4, 6>), grid2, dim3(512), lds_p, st, args, tm2, tn2);
-        } else if (wgrad_spec(a.Cm, a.Ntot)) {
-            if (a.colsum) hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4, true>), grid2, dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
-            else hipLaunchKernelGGL((igemm_wgrad_wgs_kernel<2, 4, 8, 4>), grid2, dim3(1024), lds / 3 * 4, st, args, tm2, tn2);
         } else {
             if (a.colsum) hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3, true>), grid2, dim3(512), lds, st, args, tm2, tn2);
             else hipLaunchKernelGGL((igemm_wgrad_wg_kernel<2, 4, 3>), grid2, dim3(512), lds, st, args, tm2, tn2);
@@ -3307,19 +2915,15 @@ int launch_splitk_reduce(hipStream_t st, const float* partial, float* out, size_
 // partial2 / out2 (nullable): a second job in the same launch (ReduceJob2); falls back to a launch of its own when either job has an odd element count
 int launch_splitk_reduce2(hipStream_t st, const float* partial, float* out, size_t elems, int splits, int accumulate,
                           const float* partial2, float* out2, size_t elems2, int splits2) {
-    if (DALI_ENV_INT("DALI_DEBUG_SKIP_REDUCE", 0)) return DALI_OK;      // timing aid only (wrong results): what the reduce launches cost a step
     const size_t chunks = (elems + 3) / 4;
     const unsigned rblocks = (unsigned)((chunks + 63) / 64);
     // waves per chunk column: 16 from 32 slabs on, else 4.  (An adaptive rule -- about 1024 waves per launch, at least 4 slabs per wave --
-    // measured the same standalone and 0.1 - 0.2 ms per train step SLOWER in the step, DALI_REDUCE_WAVES=-2; what made the reduce slow
+    // measured the same standalone and 0.1 - 0.2 ms per train step SLOWER in the step; what made the reduce slow
     // was the serialised loads described in the kernel, not the wave count.)  A function of (elems, splits) only, so the summation order
     // of a given weight gradient never changes from step to step.
-    int W = splits >= 32 ? 16 : (splits >= 2 ? 4 : 1);
-    const int ov = DALI_ENV_INT("DALI_REDUCE_WAVES", 0);               // A/B aid: force 1 / 2 / 4 / 8 / 16; -2 = the adaptive rule
-    if (ov == -2) { W = 1; while (W < 16 && (size_t)rblocks * W < 1024 && splits >= 8 * W) W *= 2; }
-    else if (ov > 0) W = ov;
+    const int W = splits >= 32 ? 16 : (splits >= 2 ? 4 : 1);
     const bool second = partial2 && out2 && elems2 > 0;
-    if (second && ((elems & 3) || (elems2 & 3) || !DALI_ENV_INT("DALI_REDUCE_FUSE2", 1))) {        // own launches (DALI_REDUCE_FUSE2=0: A/B aid)
+    if (second && ((elems & 3) || (elems2 & 3))) {        // own launches
         if (int rc = launch_splitk_reduce2(st, partial, out, elems, splits, accumulate, nullptr, nullptr, 0, 0)) return rc;
         return launch_splitk_reduce2(st, partial2, out2, elems2, splits2, 0, nullptr, nullptr, 0, 0);
     }
@@ -3333,9 +2937,7 @@ int launch_splitk_reduce2(hipStream_t st, const float* partial, float* out, size
     if (second) { j2 = ReduceJob2{partial2, out2, elems2, splits2, rblocks}; grid += (unsigned)((elems2 / 4 + 63) / 64); }
     switch (W) {
         case 1: hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(grid), dim3(64), 0, st, partial, out, elems, splits, accumulate, j2); break;
-        case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(grid), dim3(128), 0, st, partial, out, elems, splits, accumulate, j2); break;
         case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(grid), dim3(256), 0, st, partial, out, elems, splits, accumulate, j2); break;
-        case 8: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(grid), dim3(512), 0, st, partial, out, elems, splits, accumulate, j2); break;
         default: hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(grid), dim3(1024), 0, st, partial, out, elems, splits, accumulate, j2); break;
     }
     DALI_LAUNCH_CHECK();
@@ -3500,8 +3102,7 @@ int launch_linear_wgrad(hipStream_t st, const uint16_t* x, const uint16_t* dy, f
     linear_geom(a.g, K);
     size_t wsb;
     wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb);
-    static const bool fuse = getenv("DALI_LINEAR_BIAS_FUSED") ? atoi(getenv("DALI_LINEAR_BIAS_FUSED")) != 0 : true;      // (A/B aid)
-    const bool ride = fuse && dbias && cs_partial && wgrad_colsum_supported(N, K, 1, rows);
+    const bool ride = dbias && cs_partial && wgrad_colsum_supported(N, K, 1, rows);
     if (bias_done) *bias_done = ride;
     if (ride) a.colsum = cs_partial;
     return launch_igemm_wgrad(st, a, dw, 0, ride ? dbias : nullptr, ride ? wgrad_colsum_rows(N, K, 1, rows, a.splits) : 0);

@@ -299,7 +299,7 @@ template <int NPROD>
 __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ Q,
                                                             const float* __restrict__ gsq, const float* __restrict__ qsq,
                                                             int ng, int nq, int pitch, int ktiles, int metric, float* out,
-                                                            int tiles_m, int tiles_n, int vgrid, PairBlend blend, int stagger) {
+                                                            int tiles_m, int tiles_n, int vgrid, PairBlend blend) {
     constexpr int TM = 128, TN = 256;
     constexpr int A_ELEMS = TM * 64, B_ELEMS = TN * 64, STAGE = A_ELEMS + B_ELEMS;
     constexpr int A_PIECES = TM / 8, NDMA = (TM + TN) / 8 / 8;                   // 1 KiB DMA pieces: 16 of A, 6 per producer wave
@@ -313,14 +313,8 @@ __global__ __launch_bounds__(1024) void pairdist_dma_kernel(const uint16_t* __re
     int n_tiles = 0;
     for (int v = blockIdx.x; v < vgrid; v += gridDim.x) { int tm, tn; n_tiles += xcd_tile_map(v, tiles_m, tiles_n, tm, tn) ? 1 : 0; }
     if (n_tiles == 0) return;
-    // Staggered start (round 3; measured and OFF by default).  Hypothesis: every tile costs the same, so all 256 workgroups reach their stores
-    // together and 32 MB leave the chip in one burst while the matrix pipes idle; starting the workgroups in 8 phases an eighth of a tile
-    // apart would put each phase's stores under the others' MFMAs.  Refuted: 9.67 ms without, 10.1 - 10.5 ms with (bf16x3, 10k x 100k x 2048,
-    // interleaved in one process; bf16 4.23 -> 4.30 - 5.5): the workgroups of an XCD walking neighbouring tiles AT THE SAME TIME is what keeps
-    // their operand panels in that XCD's L2 (xcd_tile_map), and the stagger gives that up.  The stores' 8 us per tile are not burst contention.
-    // (round 4: a phase per XCD instead -- blockIdx.x & 7, the workgroups of one XCD in step, the eight XCDs' store bursts spread over a tile time --
-    // measured the same as no stagger: 8.69 / 8.73 / 8.72 ms at 1 / 2 / 3 sleep units against 8.72 without)
-    for (int i = ((int)(blockIdx.x >> 3) & 7) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+    // (Measured and removed: a staggered start of the workgroups, in 8 phases an eighth of a tile apart per workgroup -- 9.67 -> 10.1-10.5 ms, it gives up
+    // the XCD's L2 panel sharing -- or per XCD, blockIdx.x & 7 -- 8.69-8.73 against 8.72 ms.  The stores' 8 us per tile are not burst contention.)
     if (wave >= 8) {
         // ---- producer waves 8..15 (two per SIMD, next to two consumers): nothing but the DMA ring ----
         const int pw = wave - 8;
@@ -878,17 +872,9 @@ static int launch_pairdist(int num_cus, hipStream_t st, const uint16_t* g_img, c
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pairdist_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         });
         const int cap = num_cus / 8 * 8, grid = grid2 < cap ? grid2 : cap;          // persistent: one workgroup per CU (144 KiB of LDS each)
-        // stagger: s_sleep(127) units (8128 cycles, ~3.9 us) between two start phases, sized to an eighth of a tile's k-loop (48 / 32 MFMAs per
-        // wave and k-step, two waves per SIMD, 16 cycles each at ~2 GHz); only when a workgroup has several tiles.  DALI_PAIRDIST_STAGGER
-        // overrides (0 = off; A/B aid)
         const int kt = split ? Kp / 32 : Kp / 64;
-        const double tile_us = (double)kt * (split ? 48 : 32) * 2 * 16 / 2000.0;
-        int stagger = 0;                                                          // off: see the kernel
-        const int ov = DALI_ENV_INT("DALI_PAIRDIST_STAGGER", 0);                  // -1 = an eighth of a tile, n > 0 = n sleep units
-        if (ov > 0) stagger = ov;
-        else if (ov < 0 && grid2 >= 4 * grid) stagger = (int)(tile_us / 8.0 / 3.9 + 0.5);
-        if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, kt, metric, out, tm2, tn2, grid2, blend, stagger);
-        else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, kt, metric, out, tm2, tn2, grid2, blend, stagger);
+        if (split) hipLaunchKernelGGL(pairdist_dma_kernel<3>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, kt, metric, out, tm2, tn2, grid2, blend);
+        else hipLaunchKernelGGL(pairdist_dma_kernel<1>, dim3(grid), dim3(1024), lds, st, g_img, q_img, gsq, qsq, ng, nq, pitch, kt, metric, out, tm2, tn2, grid2, blend);
         DALI_LAUNCH_CHECK();
         return DALI_OK;
     }

@@ -85,20 +85,6 @@ struct dali_resnet {
     int64_t cur_dy_bytes = 0;
     bool fwd_training = false;
     int feature_mode = DALI_FEATURE_BOTH;
-    // Weight gradients beside the data-gradient chain (DALI_WGRAD_STREAM, see wgrad_fork below): a second stream with its own split-K slab,
-    // one event that carries "the operands are ready" from the main stream, one event per gradient buffer that carries "its last reader on
-    // the second stream is done" back, one event for the join.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool gbuf_busy[6] = {false, false, false, false, false, false};
-    bool side_pending = false;
-    float* wgrad_slab2 = nullptr;
-    ~dali_resnet() {
-        if (side) (void)hipStreamDestroy(side);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        for (auto e : ev_gbuf) if (e) (void)hipEventDestroy(e);
-    }
 };
 
 namespace {
@@ -159,24 +145,13 @@ GatherGeom conv_geom(const Conv& c, int mode) {
     g.lw = g.lhw = -1;
     return g;
 }
-// DALI_BNLIN=0 (A/B aid): every block keeps the materialised form (raw3 stored, bn_act, two-pass BatchNorm backward)
-bool bnlin_on() {
-    static int v = -1;
-    if (v == -1) { const char* e = getenv("DALI_BNLIN"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
-// The scheme trades passes over [P][4w] tensors for products of size w^2: it pays where P is large against w (layer1 / layer2 at batch
-// 256: 0.5 / 0.13 M pixels against w = 64 / 128).  DALI_BNLIN_MAXW moves the limit (A/B aid; measured per limit in DESIGN.md).
+// bn3 behind conv3 through the moments of conv3's input (bnlin.hip).  The scheme trades passes over [P][4w] tensors for products of size
+// w^2: it pays where P is large against w (layer1 / layer2 at batch 256: 0.5 / 0.13 M pixels against w = 64 / 128; measured per limit in
+// DESIGN.md).  DALI_BNLIN_MAXW moves the limit (0: every block keeps the materialised form).
 int bnlin_max_width() {
     static int v = -1;
     if (v == -1) { const char* e = getenv("DALI_BNLIN_MAXW"); v = e ? atoi(e) : 128; }
     return v;
-}
-// DALI_BNLIN_DS=0 (A/B aid): blocks with a downsample branch keep the materialised form
-bool bnlin_ds() {
-    static int v = -1;
-    if (v == -1) { const char* e = getenv("DALI_BNLIN_DS"); v = e ? atoi(e) : 1; }
-    return v != 0;
 }
 // a cin = cout = w 1x1 convolution on the grid of conv3: the shape of the Gram GEMM a2^T a2 and of the second data-gradient GEMM
 Conv square_conv(const Conv& c3) {
@@ -237,7 +212,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             b.hout = b.c2.hout; b.wout = b.c2.wout;
             // bn3 through the moments of a2 (bnlin.hip); in a block with a downsample branch the identity enters conv3's epilogue as
             // scale_d * rawd + shift_d (res_scale / bias) and the downsample BatchNorm keeps its own two-pass backward
-            b.lin3 = bnlin_on() && planes % 32 == 0 && planes <= bnlin_max_width() && (!b.has_ds || bnlin_ds());
+            b.lin3 = planes % 32 == 0 && planes <= bnlin_max_width();
             h = b.hout; w = b.wout; inpl = planes * 4;
             net->blocks.push_back(b);
         }
@@ -314,7 +289,6 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     reserve(net, a, net->stat_partial, max_stat);
     reserve(net, a, net->bwd_partial, max_bwd_partial);
     reserve(net, a, net->wgrad_slab, max_slab);
-    reserve(net, a, net->wgrad_slab2, max_slab);
     reserve(net, a, net->cs_partial, max_cs);
     reserve(net, a, net->stem_dw_pad, (size_t)wb * 224 * 4);
     reserve(net, a, net->red_scratch, reduce_scratch_bytes(net->feat_dim, 3));
@@ -418,69 +392,15 @@ int conv_bn_fwd(dali_resnet* net, hipStream_t st, const Conv& c, Bn& out_bn, con
     return bn_eval(net, st, out_bn);
 }
 
-// ---- weight gradients on a second stream ----------------------------------------------------------------------------------------------
-// A weight gradient is a leaf of the backward graph: nothing but the optimizer (and the data-parallel reducer) reads it, while the data
-// gradient beside it is on the critical chain, followed by the HBM-bound BatchNorm passes.  With DALI_WGRAD_STREAM=1 the weight-gradient
-// GEMM and its split-K reduce go to net->side: wgrad_fork makes that stream wait for everything the main stream has enqueued so far (the
-// operands), wgrad_readers notes which gradient buffers the launch reads, and before_write makes the MAIN stream wait for those readers
-// before any kernel that overwrites such a buffer (the six gbufs rotate).  wgrad_join makes the main stream wait for all of it: at the end
-// of the last backward stage, and on request (dali_resnet_join_grads: the data-parallel reducer, per stage).
-int side_mode() { return DALI_ENV_INT("DALI_WGRAD_STREAM", 0); }      // 1: beside everything; 2: beside the BatchNorm passes only (every main-stream GEMM joins first)
-bool side_on() { return side_mode() != 0; }
-int side_init(dali_resnet* net) {
-    if (net->side) return DALI_OK;
-    DALI_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
-    DALI_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
-    DALI_HIP(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
-    for (auto& e : net->ev_gbuf) DALI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    return DALI_OK;
-}
-int wgrad_fork(dali_resnet* net, hipStream_t st) {
-    if (int rc = side_init(net)) return rc;
-    DALI_HIP(hipEventRecord(net->ev_fork, st));
-    DALI_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
-    net->side_pending = true;
-    return DALI_OK;
-}
-int wgrad_readers(dali_resnet* net, const uint16_t* b0, const uint16_t* b1) {
-    for (int i = 0; i < 6; ++i)
-        if (net->gbuf[i] == b0 || net->gbuf[i] == b1) {
-            DALI_HIP(hipEventRecord(net->ev_gbuf[i], net->side));
-            net->gbuf_busy[i] = true;
-        }
-    return DALI_OK;
-}
-int before_write(dali_resnet* net, hipStream_t st, const uint16_t* buf) {
-    for (int i = 0; i < 6; ++i)
-        if (net->gbuf[i] == buf && net->gbuf_busy[i]) {
-            DALI_HIP(hipStreamWaitEvent(st, net->ev_gbuf[i], 0));
-            net->gbuf_busy[i] = false;
-        }
-    return DALI_OK;
-}
-int wgrad_join(dali_resnet* net, hipStream_t st) {
-    if (!net->side_pending) return DALI_OK;
-    DALI_HIP(hipEventRecord(net->ev_join, net->side));
-    DALI_HIP(hipStreamWaitEvent(st, net->ev_join, 0));
-    net->side_pending = false;
-    for (auto& b : net->gbuf_busy) b = false;
-    return DALI_OK;
-}
-
 int conv_wgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* x, const Bn* in_bn, const uint16_t* dy) {
     WGradArgs a{};
-    const bool side = side_on();
-    a.dY = dy; a.X = x; a.partial = side ? net->wgrad_slab2 : net->wgrad_slab;
+    a.dY = dy; a.X = x; a.partial = net->wgrad_slab;
     a.in_scale = in_bn ? in_bn->scale : nullptr; a.in_shift = in_bn ? in_bn->shift : nullptr; a.in_relu = in_bn ? 1 : 0;
     a.Cm = c.cout; a.P = net->N * c.hout * c.wout; a.Ntot = c.r * c.s * c.cin;
     a.g = conv_geom(c, 0);
     size_t wsb;
     wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb, c.r * c.s, in_bn ? 0 : conv_halo_w(c));
-    if (!side) return launch_igemm_wgrad(st, a, net->G + c.w_off, 0);
-    int rc;
-    if ((rc = wgrad_fork(net, st))) return rc;
-    if ((rc = launch_igemm_wgrad(net->side, a, net->G + c.w_off, 0))) return rc;
-    return wgrad_readers(net, dy, x);
+    return launch_igemm_wgrad(st, a, net->G + c.w_off, 0);
 }
 
 // out_mask: ReLU mask of the block output this gradient belongs to (the masked gradient dz = dy * (y > 0) is what every block stores)
@@ -491,8 +411,6 @@ int conv_dgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* 
     a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0; a.stats = nullptr;
     a.Cm = c.cin; a.P = net->N * c.hin * c.win;
     a.g = conv_geom(c, 1);
-    if (int rc = before_write(net, st, dx)) return rc;
-    if (side_mode() == 2) { if (int rc = wgrad_join(net, st)) return rc; }
     return launch_igemm_conv(st, a);
 }
 
@@ -607,7 +525,6 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
         const bool fused_cs = wgrad_colsum_supported(wa.Cm, wa.Ntot, 1, wa.P);              // s = colsum(dz) rides on the weight-gradient GEMM
         if (fused_cs) wa.colsum = net->cs_partial;
-        if (side_mode() == 2 && (rc = wgrad_join(net, st))) return rc;
         if ((rc = launch_igemm_wgrad(st, wa, net->G + b.c3.w_off, 0, fused_cs ? b.sdz : nullptr,
                                      fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;           // G0 = dz^T a2 into the gradient slot; finished in place below
         if (!fused_cs && (rc = launch_colsum(st, dz, Pout, b.cout, b.sdz, net->cs_partial, net->red_scratch))) return rc;
@@ -621,7 +538,6 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         if (b.has_ds) {                                           // the downsample BatchNorm: its own two passes over (dz, rawd)
             d_rawd = next_gbuf(net, dz, d_a2, scratch_a);
             BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
-            if ((rc = before_write(net, st, d_rawd))) return rc;
             if ((rc = launch_bn_bwd(st, dz, nullptr, nullptr, sd, nullptr, 0, Pout, b.cout, net->bwd_partial, b.bd.coef, nullptr, net->G + b.bd.g_off,
                                     net->G + b.bd.b_off, nullptr, nullptr, d_rawd, nullptr, nullptr, net->red_scratch))) return rc;
         }
@@ -630,40 +546,32 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         d_rawd = b.has_ds ? next_gbuf(net, dz, d_raw3) : nullptr;
         BnBwdSide s3{b.raw3, b.b3.mean, b.b3.invstd, b.b3.scale, b.b3.shift};
         BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
-        if ((rc = before_write(net, st, d_raw3))) return rc;
-        if (d_rawd && (rc = before_write(net, st, d_rawd))) return rc;
         rc = launch_bn_bwd(st, dz, nullptr, nullptr, s3, b.has_ds ? &sd : nullptr, 0, Pout, b.cout, net->bwd_partial, b.b3.coef, b.has_ds ? b.bd.coef : nullptr,
                            net->G + b.b3.g_off, net->G + b.b3.b_off, b.has_ds ? net->G + b.bd.g_off : nullptr, b.has_ds ? net->G + b.bd.b_off : nullptr,
                            d_raw3, d_rawd, nullptr, net->red_scratch);
         if (rc) return rc;
-        const bool late = side_mode() == 2;                       // mode 2: the weight gradient is enqueued behind its data gradient
-        if (!late && (rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
+        if ((rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
         d_a2 = next_gbuf(net, dz, d_raw3, d_rawd);
         if ((rc = conv_dgrad(net, st, b.c3, d_raw3, nullptr, d_a2))) return rc;
-        if (late && (rc = conv_wgrad(net, st, b.c3, b.a2, nullptr, d_raw3))) return rc;
         scratch_a = d_raw3;                                       // d_raw3 is dead from here on
     }
     // bn2 + relu, in place.  The ReLU mask is recomputed from raw2 (raw*scale+shift > 0 <=> a2 > 0: bf16 rounding cannot
     // flush a positive fp32 to zero) instead of reading a2: one tensor read less in each of the two passes.
     BnBwdSide s2{b.raw2, b.b2.mean, b.b2.invstd, b.b2.scale, b.b2.shift};
-    if ((rc = before_write(net, st, d_a2))) return rc;
     if ((rc = launch_bn_bwd(st, d_a2, nullptr, nullptr, s2, nullptr, 1, Pout, b.width, net->bwd_partial, b.b2.coef, nullptr, net->G + b.b2.g_off,
                             net->G + b.b2.b_off, nullptr, nullptr, d_a2, nullptr, nullptr, net->red_scratch))) return rc;
     // conv2
-    const bool late = side_mode() == 2;
-    if (!late && (rc = conv_wgrad(net, st, b.c2, b.a1, nullptr, d_a2))) return rc;
+    if ((rc = conv_wgrad(net, st, b.c2, b.a1, nullptr, d_a2))) return rc;
     uint16_t* d_a1 = scratch_a;
     if ((rc = conv_dgrad(net, st, b.c2, d_a2, nullptr, d_a1))) return rc;
-    if (late && (rc = conv_wgrad(net, st, b.c2, b.a1, nullptr, d_a2))) return rc;
     BnBwdSide s1{b.raw1, b.b1.mean, b.b1.invstd, b.b1.scale, b.b1.shift};
-    if ((rc = before_write(net, st, d_a1))) return rc;
     if ((rc = launch_bn_bwd(st, d_a1, nullptr, nullptr, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
                             net->G + b.b1.b_off, nullptr, nullptr, d_a1, nullptr, nullptr, net->red_scratch))) return rc;
     // conv1 (+ identity / downsample branch); the result is masked with the previous block's ReLU bits
-    if (!late && (rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
+    if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
     uint16_t* dx = d_a2;                                          // d_a2 is dead now
     if (b.has_ds) {
-        if (!late && (rc = conv_wgrad(net, st, b.cd, b.x, nullptr, d_rawd))) return rc;
+        if ((rc = conv_wgrad(net, st, b.cd, b.x, nullptr, d_rawd))) return rc;
         // conv1's data gradient first, then the downsample branch accumulates into it in place: with stride 2 only the
         // even-even quarter of the positions receives a contribution (launch_igemm_conv's parity split).  (a + b) * m = a * m + b * m:
         // both launches apply the mask.
@@ -671,10 +579,6 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         if ((rc = conv_dgrad(net, st, b.cd, d_rawd, dx, dx, prev_bits))) return rc;
     } else {
         if ((rc = conv_dgrad(net, st, b.c1, d_a1, dz, dx, prev_bits))) return rc;             // identity path: + dz
-    }
-    if (late) {
-        if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
-        if (b.has_ds && (rc = conv_wgrad(net, st, b.cd, b.x, nullptr, d_rawd))) return rc;
     }
     net->cur_dy = dx;
     net->cur_dy_bytes = (int64_t)Pin * b.cin * 2;
@@ -696,7 +600,6 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
             if ((rc = launch_bn1d_bwd(st, net->feat, d_emb, net->N, net->feat_dim, net->P + net->neck.g_off, net->neck_mean, net->neck_invstd,
                                       net->dfeat, net->G + net->neck.g_off, net->G + net->neck.b_off))) return rc;
             net->cur_dy = net->gbuf[0];
-            if ((rc = before_write(net, st, net->cur_dy))) return rc;
             if ((rc = launch_head_pool_bwd(st, net->dfeat, net->head_arg, net->N, net->head_hw, net->feat_dim, net->feature_mode, net->cur_dy,
                                            net->blocks.back().ybits))) return rc;
             net->cur_dy_bytes = (int64_t)net->N * net->head_hw * net->feat_dim * 2;
@@ -706,31 +609,20 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
         if (stage == 3) {
             // maxpool + stem BN backward, then the stem weight gradient (no data gradient: images need none)
             uint16_t* d_raw0 = next_gbuf(net, net->cur_dy);
-            if ((rc = before_write(net, st, d_raw0))) return rc;
             if ((rc = launch_maxpool_bn_bwd(st, net->cur_dy, net->pool_arg, net->raw0, net->stem_bn.mean, net->stem_bn.invstd, net->stem_bn.scale,
                                             net->N, net->stem_h, net->stem_w, net->stem.cout, net->bwd_partial, net->stem_bn.coef,
                                             net->G + net->stem_bn.g_off, net->G + net->stem_bn.b_off, d_raw0, net->red_scratch))) return rc;
             WGradArgs a{};
-            const bool side = side_on();
-            hipStream_t ws = st;
-            if (side) { if ((rc = wgrad_fork(net, st))) return rc; ws = net->side; }
-            a.dY = d_raw0; a.X = net->ximg; a.partial = side ? net->wgrad_slab2 : net->wgrad_slab; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
+            a.dY = d_raw0; a.X = net->ximg; a.partial = net->wgrad_slab; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
             a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w; a.Ntot = 224;
             a.g = stem_geom(net);
             size_t wsb;
             wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb);
-            if ((rc = launch_igemm_wgrad(ws, a, net->stem_dw_pad, 0))) return rc;
-            if ((rc = launch_stem_unpack_wgrad(ws, net->stem_dw_pad, net->stem.cout, net->G + net->stem.w_off))) return rc;
-            if (side && (rc = wgrad_readers(net, d_raw0, nullptr))) return rc;
+            if ((rc = launch_igemm_wgrad(st, a, net->stem_dw_pad, 0))) return rc;
+            if ((rc = launch_stem_unpack_wgrad(st, net->stem_dw_pad, net->stem.cout, net->G + net->stem.w_off))) return rc;
         }
     }
-    if (stage_end == 3) return wgrad_join(net, st);          // earlier stages: dali_resnet_join_grads, when their gradients are needed before the last one's
     return DALI_OK;
-}
-
-extern "C" int dali_resnet_join_grads(dali_resnet* net, void* stream) {
-    DALI_REQUIRE(net, "dali_resnet_join_grads: null net");
-    return wgrad_join(net, (hipStream_t)stream);
 }
 
 // Debug/inspection: device pointer + byte size of a named intermediate (valid after a forward).

@@ -283,20 +283,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __r
 // Multi-head self-attention, one block per (batch, head); head_dim 64; T <= 16 * NTILE tokens, NTILE in {13, 14, 16}
 // (197 tokens = ViT-B/16 at 224x224; 211 = TransReID's 256x128 at stride 12, vit_pytorch.py:254-267; up to 256).
 // qkv [B*T][3C] bf16 (q | k | v, head h at columns h*64 of each third, as vit_pytorch.py:155 lays them out).
-// Forward: O = softmax(Q K^T * scale) V, scores never leave the chip.  Per wave: 16 query rows at a time:
-//   S (16 x Tp) by MFMA from LDS-resident Q, K  ->  row softmax in registers  ->  P (bf16) through a per-wave LDS
-//   strip  ->  O = P V with V consumed through ds_read_b64_tr_b16 (key-major storage, k = key).
-// Also writes the row log-sum-exp (lse = max + log(sum)) for the backward.
+// Forward: O = softmax(Q K^T * scale) V, scores never leave the chip; also writes the row log-sum-exp (lse = max + log(sum)) for the
+// backward.  The kernels are the "second form" described further down (attention_fwd2 / bwd_dq / bwd_dkv: probabilities stay in registers);
+// the first form (P through a per-wave LDS strip, one workgroup per CU: 90 us forward, 316 us backward per layer) was removed in round 4.
 // LDS images are plain row-major [Tp][72] bf16 (64 + 8 pad): both the K-contiguous (ds_read_b128) and the transposing
 // (tr_b16) fragment reads work on it.
 // ------------------------------------------------------------------------------------------------
-constexpr int ATT_LD = 72, ATT_HD = 64, ATT_SW = 128;   // ATT_SW: columns of a half strip
+constexpr int ATT_LD = 72, ATT_HD = 64;
 constexpr int ATT_MAX_T = 256;
-// geometry of an NTILE-tile instance: TP = token rows of the images, second strip half = tiles 8 .. 8 + H2 - 1 (H2 even: whole
-// k-steps of 32 keys; tiles >= NTILE are zero), PK = rows the transposing reads of the P V / dS K loops may touch
-template <int NTILE> struct AttGeom {
-    static constexpr int TP = NTILE * 16, H2 = (NTILE - 8 + 1) / 2 * 2, PK = (8 + H2) * 16;
-};
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef short s16x8v __attribute__((ext_vector_type(8)));
 
@@ -304,17 +298,6 @@ typedef short s16x8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8_t frag_k(const uint16_t* base, int ld, int row0, int k0, int lane) {
     return *reinterpret_cast<const bf16x8_t*>(base + (row0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
 }
-// fragment whose k index is the ROW of the LDS image: rows k0 + 8*(lane>>4) .. +7, column n0 + (lane&15)
-__device__ __forceinline__ bf16x8_t frag_tr(const uint16_t* base, int ld, int k0, int n0, int lane) {
-    typedef __attribute__((address_space(3))) s16x4v* lp;
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const uint16_t* a0 = base + (k0 + 8 * g + q) * ld + n0 + 4 * p;
-    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a0);
-    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a0 + 4 * ld));
-    const s16x8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, v);
-}
-
 template <int TP>
 __device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, size_t row_stride, int T, uint16_t* dst) {
     // [T][64] bf16 from global (row stride in elements) -> LDS [TP][ATT_LD], rows >= T zeroed
@@ -323,247 +306,6 @@ __device__ __forceinline__ void att_load_tile(const uint16_t* __restrict__ src, 
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < T) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
         *reinterpret_cast<uint4*>(dst + row * ATT_LD + ch * 8) = v;
-    }
-}
-
-// NW waves per (batch, head), one query tile per wave where the LDS allows (13 waves at 197 tokens; 4 waves: 4 rounds, 134 us per
-// layer; 8 waves: 89 us).  A wave's P strip holds half of the keys at a time ([16][128] bf16: tiles 0..7, then tiles 8..8+H2-1), so
-// the strips fit beside Q, K, V.
-template <int NTILE, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int T, int H, float scale,
-                                                             uint16_t* __restrict__ out, float* __restrict__ lse) {
-    constexpr int ATT_TP = AttGeom<NTILE>::TP, ATT_PK = AttGeom<NTILE>::PK, H2 = AttGeom<NTILE>::H2, ATT_FWD_NW = NW;
-    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
-    uint16_t* sQ = sm;
-    uint16_t* sK = sQ + ATT_TP * ATT_LD;
-    uint16_t* sV = sK + ATT_TP * ATT_LD;
-    uint16_t* sP = sV + (ATT_PK) * ATT_LD;                         // V padded to PK rows (zero) for the k loop of P V
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
-    const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t rs = (size_t)3 * C;
-    const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
-    att_load_tile<ATT_TP>(base, rs, T, sQ);
-    att_load_tile<ATT_TP>(base + C, rs, T, sK);
-    att_load_tile<ATT_TP>(base + 2 * C, rs, T, sV);
-    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += ATT_FWD_NW * 64) sV[ATT_TP * ATT_LD + i] = 0;
-    __syncthreads();
-    uint16_t* myP = sP + wave * 16 * ATT_SW;
-    for (int qt = wave; qt < ATT_TP / 16; qt += ATT_FWD_NW) {
-        if (qt * 16 >= T) break;
-        const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
-        // Score tiles are computed TRANSPOSED (rows = keys, columns = this tile's 16 queries): a lane owns ONE query (lane&15)
-        // and 4 consecutive keys per tile, so the softmax statistics are one value per lane, the cross-lane part is two
-        // shuffles over the 4 lane groups, and P goes to the [query][key] strip with 8-byte writes.
-        f32x4_t s[ATT_TP / 16];
-        const float sc2 = scale * 1.44269504088896f;                 // exp(x) = 2^(x log2 e)
-        float m = -__builtin_inff();
-#pragma unroll
-        for (int j = 0; j < ATT_TP / 16; ++j) {
-            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, a, 0, 0, 0);
-            const int key0 = j * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = (key0 + r < T) ? a[r] * sc2 : -__builtin_inff(); m = fmaxf(m, a[r]); }
-            s[j] = a;
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int j = 0; j < ATT_TP / 16; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[j][r] = __builtin_amdgcn_exp2f(s[j][r] - m); l += s[j][r]; }
-        l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
-        const float inv_l = 1.0f / l;
-        if (lane < 16) {
-            const int row = qt * 16 + lane;
-            if (row < T && lse) lse[(size_t)bh * T + row] = (m + log2f(l)) * 0.6931471805599453f;     // natural-log lse = max + log(sum)
-        }
-        // O = P V : A = P (k = key, contiguous) from the per-wave strip, B[k = key][n = d] = V[key][d] through the transposing read
-        f32x4_t o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-            for (int jj = 0; jj < (hf == 0 ? 8 : H2); ++jj) {
-                const int j = hf * 8 + jj;
-                uint2 pv = make_uint2(0u, 0u);
-                if (j < ATT_TP / 16) pv = make_uint2(pack_bf16x2(s[j < ATT_TP / 16 ? j : 0][0] * inv_l, s[j < ATT_TP / 16 ? j : 0][1] * inv_l),
-                                                      pack_bf16x2(s[j < ATT_TP / 16 ? j : 0][2] * inv_l, s[j < ATT_TP / 16 ? j : 0][3] * inv_l));
-                *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = pv;
-            }
-#pragma unroll
-            for (int kk = 0; kk < (hf == 0 ? 4 : H2 / 2); ++kk) {
-                const bf16x8_t pa = frag_k(myP, ATT_SW, 0, kk * 32, lane);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(sV, ATT_LD, hf * 128 + kk * 32, d * 16, lane), o[d], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = qt * 16 + (lane >> 4) * 4 + r;
-                if (row < T) out[((size_t)b * T + row) * C + h * ATT_HD + d * 16 + (lane & 15)] = f32_to_bf16_bits(o[d][r]);
-            }
-    }
-}
-
-// Backward.  Pass A (a wave owns 16 query rows): recompute P from Q, K and the saved lse; dP = dO V^T;
-// D_i = rowsum(dO * O); dS = P * (dP - D_i) * scale; dQ = dS K (K through the transposing read).  dS and P strips are kept
-// nowhere: pass B (a wave owns 16 keys) recomputes S^T = K Q^T, P^T, dP^T = V dO^T and forms dK = dS^T Q, dV = P^T dO
-// with Q / dO consumed through the transposing read.  No cross-block reduction, no atomics.
-// 8 waves per (batch, head): 13 query / key tiles in 2 rounds instead of 4.  Four [224][72] images leave 32 KiB for the strips,
-// so a wave's strip holds HALF of the keys (queries) at a time: [16][128] bf16, tiles 0..7 then tiles 8..12 (+ one zero tile),
-// each half followed by its share of the second GEMM (4 resp. 3 k-steps of 32).
-// (beyond 224 tokens the four [256][72] images leave room for 3 strips only: a 3-wave instance, slow but complete)
-template <int NTILE, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
-                                                                        const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                                        int B, int T, int H, float scale, uint16_t* __restrict__ dqkv) {
-    constexpr int ATT_TP = AttGeom<NTILE>::TP, ATT_PK = AttGeom<NTILE>::PK, H2 = AttGeom<NTILE>::H2, ATT_BWD_NW = NW;
-    constexpr int NT = ATT_BWD_NW * 64;
-    extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
-    uint16_t* sQ = sm;
-    uint16_t* sK = sQ + ATT_PK * ATT_LD;
-    uint16_t* sV = sK + ATT_PK * ATT_LD;
-    uint16_t* sD = sV + ATT_PK * ATT_LD;                           // dO
-    uint16_t* sP = sD + ATT_PK * ATT_LD;                           // per-wave strips [NW][16][128]
-    float* sLse = reinterpret_cast<float*>(sP + ATT_BWD_NW * 16 * ATT_SW);  // [224]
-    float* sDi = sLse + ATT_PK;                                    // [224]
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
-    const int C = H * ATT_HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t rs = (size_t)3 * C;
-    const uint16_t* base = qkv + (size_t)b * T * rs + h * ATT_HD;
-    att_load_tile<ATT_TP>(base, rs, T, sQ);
-    att_load_tile<ATT_TP>(base + C, rs, T, sK);
-    att_load_tile<ATT_TP>(base + 2 * C, rs, T, sV);
-    att_load_tile<ATT_TP>(d_o + (size_t)b * T * C + h * ATT_HD, C, T, sD);
-    for (int i = threadIdx.x; i < (ATT_PK - ATT_TP) * ATT_LD; i += NT) {
-        sQ[ATT_TP * ATT_LD + i] = 0; sK[ATT_TP * ATT_LD + i] = 0; sV[ATT_TP * ATT_LD + i] = 0; sD[ATT_TP * ATT_LD + i] = 0;
-    }
-    // D_i = sum_d dO[i][d] * O[i][d] (8 lanes x 16 bytes per row, coalesced; reduced over the 8 lanes); lse
-    for (int i0 = 0; i0 < ATT_PK; i0 += NT / 8) {
-        const int i = i0 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
-        float acc = 0.f;
-        if (i < T) {
-            float ov[8], gv[8];
-            unpack8v(*reinterpret_cast<const uint4*>(o + ((size_t)b * T + i) * C + h * ATT_HD + ch * 8), ov);
-            unpack8v(*reinterpret_cast<const uint4*>(d_o + ((size_t)b * T + i) * C + h * ATT_HD + ch * 8), gv);
-#pragma unroll
-            for (int d = 0; d < 8; ++d) acc += ov[d] * gv[d];
-        }
-        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-        if (ch == 0 && i < ATT_PK) sDi[i] = acc;
-    }
-    for (int i = threadIdx.x; i < ATT_PK; i += NT) sLse[i] = (i < T) ? lse[(size_t)bh * T + i] : 0.f;
-    __syncthreads();
-    uint16_t* myP = sP + wave * 16 * ATT_SW;
-    uint16_t* dq_base = dqkv + (size_t)b * T * rs + h * ATT_HD;
-    const float sc2 = scale * 1.44269504088896f;
-    // ---- pass A: dQ ----
-    for (int qt = wave; qt < NTILE; qt += ATT_BWD_NW) {
-        if (qt * 16 >= T) break;
-        const bf16x8_t qa0 = frag_k(sQ, ATT_LD, qt * 16, 0, lane), qa1 = frag_k(sQ, ATT_LD, qt * 16, 32, lane);
-        const bf16x8_t ga0 = frag_k(sD, ATT_LD, qt * 16, 0, lane), ga1 = frag_k(sD, ATT_LD, qt * 16, 32, lane);
-        // score tiles are computed TRANSPOSED (rows = keys, columns = this tile's queries): a lane then holds 4 consecutive
-        // keys of one query = one 8-byte write into the [query][key] strip (the un-transposed form needed four 2-byte writes)
-        const float lq = sLse[qt * 16 + (lane & 15)] * 1.44269504088896f, dq_i = sDi[qt * 16 + (lane & 15)];
-        f32x4_t dq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-            for (int jj = 0; jj < (hf == 0 ? 8 : H2); ++jj) {       // second half: tiles 8..NTILE-1 (+ a zero tile when NTILE is odd)
-                const int j = hf * 8 + jj;
-                const int key0 = j * 16 + (lane >> 4) * 4;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (j < NTILE) {
-                    f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 0, lane), qa0, sc, 0, 0, 0);
-                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sK, ATT_LD, j * 16, 32, lane), qa1, sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 0, lane), ga0, dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sV, ATT_LD, j * 16, 32, lane), ga1, dp, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = (key0 + r < T) ? __builtin_amdgcn_exp2f(sc[r] * sc2 - lq) : 0.f;
-                        v[r] = p * (dp[r] - dq_i) * scale;
-                    }
-                }
-                *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
-#pragma unroll
-            for (int kk = 0; kk < (hf == 0 ? 4 : H2 / 2); ++kk) {
-                const bf16x8_t da = frag_k(myP, ATT_SW, 0, kk * 32, lane);
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, frag_tr(sK, ATT_LD, hf * 128 + kk * 32, d * 16, lane), dq[d], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = qt * 16 + (lane >> 4) * 4 + r;
-                if (row < T) dq_base[(size_t)row * rs + d * 16 + (lane & 15)] = f32_to_bf16_bits(dq[d][r]);
-            }
-    }
-    // ---- pass B: dK, dV (rows = keys, columns = queries) ----
-    for (int kt = wave; kt < NTILE; kt += ATT_BWD_NW) {
-        if (kt * 16 >= T) break;
-        const bf16x8_t ka0 = frag_k(sK, ATT_LD, kt * 16, 0, lane), ka1 = frag_k(sK, ATT_LD, kt * 16, 32, lane);
-        const bf16x8_t va0 = frag_k(sV, ATT_LD, kt * 16, 0, lane), va1 = frag_k(sV, ATT_LD, kt * 16, 32, lane);
-        f32x4_t dk[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        f32x4_t dv[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const bool key_ok = kt * 16 + (lane & 15) < T;
-        // P^T strip first (for dV), then dS^T (for dK): two sweeps over the queries, each in two halves
-        for (int sweep = 0; sweep < 2; ++sweep) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-                for (int jj = 0; jj < (hf == 0 ? 8 : H2); ++jj) {   // query tile j = 8 hf + jj
-                    const int j = hf * 8 + jj;
-                    const int q0 = j * 16 + (lane >> 4) * 4;       // first of this lane's 4 queries
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (j < NTILE) {
-                        // rows = queries of tile j, columns = this tile's keys: 4 consecutive queries of one key per lane = one
-                        // 8-byte write into the [key][query] strip
-                        f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-                        st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 0, lane), ka0, st, 0, 0, 0);
-                        st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sQ, ATT_LD, j * 16, 32, lane), ka1, st, 0, 0, 0);
-                        if (sweep == 1) {
-                            dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 0, lane), va0, dpt, 0, 0, 0);
-                            dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(sD, ATT_LD, j * 16, 32, lane), va1, dpt, 0, 0, 0);
-                        }
-                        const float4 lq4 = *reinterpret_cast<const float4*>(sLse + q0), dq4 = *reinterpret_cast<const float4*>(sDi + q0);
-                        const float lqv[4] = {lq4.x, lq4.y, lq4.z, lq4.w}, dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float p = (key_ok && q0 + r < T) ? __builtin_amdgcn_exp2f((st[r] * scale - lqv[r]) * 1.44269504088896f) : 0.f;
-                            v[r] = sweep == 0 ? p : p * (dpt[r] - dqv[r]) * scale;
-                        }
-                    }
-                    *reinterpret_cast<uint2*>(myP + (lane & 15) * ATT_SW + jj * 16 + (lane >> 4) * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                }
-#pragma unroll
-                for (int kk = 0; kk < (hf == 0 ? 4 : H2 / 2); ++kk) {
-                    const bf16x8_t a = frag_k(myP, ATT_SW, 0, kk * 32, lane);
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        if (sweep == 0) dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sD, ATT_LD, hf * 128 + kk * 32, d * 16, lane), dv[d], 0, 0, 0);
-                        else dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sQ, ATT_LD, hf * 128 + kk * 32, d * 16, lane), dk[d], 0, 0, 0);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + (lane >> 4) * 4 + r;
-                if (key < T) {
-                    dq_base[(size_t)key * rs + C + d * 16 + (lane & 15)] = f32_to_bf16_bits(dk[d][r]);
-                    dq_base[(size_t)key * rs + 2 * C + d * 16 + (lane & 15)] = f32_to_bf16_bits(dv[d][r]);
-                }
-            }
     }
 }
 
@@ -635,8 +377,8 @@ int launch_layernorm_fwd(hipStream_t st, const uint16_t* x, const float* gamma, 
 }
 // LayerNorm backward: TWO workgroups per CU in one round (the kernel needs ~200 VGPRs = two 4-wave workgroups per CU; the former 768
 // "three per CU" ran as one and a half rounds): 25216 rows x 768, with the reduce behind it, 47.5 us at 768 -> 43.3 at 512, 40.4 with two
-// rows of requests ahead; three waves per SIMD spill (59.6 us), four 93.7.  DALI_LN_BLOCKS / DALI_LN_WAVES override (A/B aids).
-static int ln_block_cap() { return DALI_ENV_INT("DALI_LN_BLOCKS", 512); }
+// rows of requests ahead; three waves per SIMD spill (59.6 us), four 93.7.
+static int ln_block_cap() { return 512; }
 static int rows_blocks(int rows, int per_iter, int* rpb, int cap = 2048) {
     int blocks = (rows + per_iter * 8 - 1) / (per_iter * 8);
     if (blocks > cap) blocks = cap;                    // column sums: 8 workgroups per CU (512 left too few rows in flight: 26 -> 17 us)
@@ -653,10 +395,7 @@ int launch_layernorm_bwd(hipStream_t st, const uint16_t* g, const uint16_t* x, c
     int rpb;
     const int blocks = rows_blocks(rows, 4, &rpb, ln_block_cap());
     const size_t lds = (size_t)4 * C * 2 * sizeof(float);
-    const int minw = DALI_ENV_INT("DALI_LN_WAVES", 2);                     // A/B aid: 2 (default bound), 3, 4 waves per SIMD for the C <= 1024 instantiation
     if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
-    else if (C <= 1024 && minw == 3) hipLaunchKernelGGL((layernorm_bwd_kernel<2, 3>), dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
-    else if (C <= 1024 && minw == 4) hipLaunchKernelGGL((layernorm_bwd_kernel<2, 4>), dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<LN_MAXCH>, dim3(blocks), dim3(256), lds, st, g, x, gamma, mean, rstd, add, rows, C, rpb, dx, partial, g32);
     DALI_LAUNCH_CHECK();
@@ -961,32 +700,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_dkv_kernel(const uin
 template <int NTILE> constexpr size_t att2_lds() { return (size_t)2 * NTILE * 16 * ATT_LD * 2 + 2 * NTILE * 16 * 4; }
 static_assert(2 * att2_lds<16>() <= 163840, "two attention workgroups per CU");
 
-template <int NTILE, int NW> constexpr size_t att_fwd_lds() {
-    return ((size_t)2 * AttGeom<NTILE>::TP * ATT_LD + (size_t)AttGeom<NTILE>::PK * ATT_LD + NW * 16 * ATT_SW) * 2;
-}
-template <int NTILE, int NW> constexpr size_t att_bwd_lds() {
-    return ((size_t)4 * AttGeom<NTILE>::PK * ATT_LD + NW * 16 * ATT_SW) * 2 + 2 * AttGeom<NTILE>::PK * 4;
-}
-static_assert(att_fwd_lds<13, 13>() <= 163840 && att_fwd_lds<14, 14>() <= 163840 && att_fwd_lds<16, 12>() <= 163840, "attention forward LDS");
-static_assert(att_bwd_lds<13, 8>() <= 163840 && att_bwd_lds<14, 8>() <= 163840 && att_bwd_lds<16, 3>() <= 163840, "attention backward LDS");
-
-template <int NTILE, int NW>
-static int att_fwd_launch(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
-    constexpr size_t lds = att_fwd_lds<NTILE, NW>();
-    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel<NTILE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((attention_fwd_kernel<NTILE, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, B, T, H, scale, out, lse);
-    DALI_LAUNCH_CHECK();
-    return DALI_OK;
-}
-template <int NTILE, int NW>
-static int att_bwd_launch(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
-                          float scale, uint16_t* dqkv) {
-    constexpr size_t lds = att_bwd_lds<NTILE, NW>();
-    DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<NTILE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((attention_bwd_kernel<NTILE, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
-    DALI_LAUNCH_CHECK();
-    return DALI_OK;
-}
 template <int NTILE, int NW>
 static int att2_fwd_launch(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
     constexpr size_t lds = att2_lds<NTILE>();
@@ -1006,29 +719,18 @@ static int att2_bwd_launch(hipStream_t st, const uint16_t* qkv, const uint16_t* 
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
-// DALI_ATT_V1=1 (A/B aid): the first form (P through per-wave LDS strips, one workgroup per CU)
 int launch_attention_fwd(hipStream_t st, const uint16_t* qkv, int B, int T, int H, float scale, uint16_t* out, float* lse) {
-    if (!DALI_ENV_INT("DALI_ATT_V1", 0)) {
-        if (T <= 208) return att2_fwd_launch<13, 7>(st, qkv, B, T, H, scale, out, lse);
-        if (T <= 224) return att2_fwd_launch<14, 7>(st, qkv, B, T, H, scale, out, lse);
-        if (T <= 256) return att2_fwd_launch<16, 8>(st, qkv, B, T, H, scale, out, lse);
-    }
-    if (T <= 208) return att_fwd_launch<13, 13>(st, qkv, B, T, H, scale, out, lse);
-    if (T <= 224) return att_fwd_launch<14, 14>(st, qkv, B, T, H, scale, out, lse);
-    if (T <= 256) return att_fwd_launch<16, 12>(st, qkv, B, T, H, scale, out, lse);
+    if (T <= 208) return att2_fwd_launch<13, 7>(st, qkv, B, T, H, scale, out, lse);
+    if (T <= 224) return att2_fwd_launch<14, 7>(st, qkv, B, T, H, scale, out, lse);
+    if (T <= 256) return att2_fwd_launch<16, 8>(st, qkv, B, T, H, scale, out, lse);
     set_error("attention: %d tokens exceed the limit of %d", T, ATT_MAX_T);
     return DALI_ERR_LIMIT;
 }
 int launch_attention_bwd(hipStream_t st, const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int B, int T, int H,
                          float scale, uint16_t* dqkv) {
-    if (!DALI_ENV_INT("DALI_ATT_V1", 0)) {
-        if (T <= 208) return att2_bwd_launch<13, 7>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
-        if (T <= 224) return att2_bwd_launch<14, 7>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
-        if (T <= 256) return att2_bwd_launch<16, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
-    }
-    if (T <= 208) return att_bwd_launch<13, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
-    if (T <= 224) return att_bwd_launch<14, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
-    if (T <= 256) return att_bwd_launch<16, 3>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    if (T <= 208) return att2_bwd_launch<13, 7>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    if (T <= 224) return att2_bwd_launch<14, 7>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
+    if (T <= 256) return att2_bwd_launch<16, 8>(st, qkv, o, d_o, lse, B, T, H, scale, dqkv);
     set_error("attention: %d tokens exceed the limit of %d", T, ATT_MAX_T);
     return DALI_ERR_LIMIT;
 }

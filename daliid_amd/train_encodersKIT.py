@@ -195,8 +195,6 @@ class trainer(object):
         for stage in range(n_stages):                                                 # :215 backward
             net._backward_stage(d_emb, stage)
             if self._dp is not None:
-                if hasattr(net, "join_grads"):
-                    net.join_grads()                                                  # weight gradients may run on the plan's second stream
                 self._dp.reduce_stage(stage)
         if self._dp is not None:
             self._dp.finish()

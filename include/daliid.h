@@ -388,10 +388,7 @@ int dali_resnet_forward(dali_resnet* net, void* stream, const float* images, int
  * 2: layer2, 3: layer1+stem); fills the flat gradient buffer (overwrites, no accumulation).
  * Stands under `batch_loss.backward()` (train_encodersKIT.py:215). */
 int dali_resnet_backward(dali_resnet* net, void* stream, const float* d_emb, int stage_begin, int stage_end);
-/* The library may run a stage's weight-gradient GEMMs on a stream of its own beside the data-gradient chain (DALI_WGRAD_STREAM=1).  The flat
- * gradient buffer is complete on `stream` after the call that runs stage 3, or after this call for the stages run so far (the data-parallel
- * reducer calls it per stage before it reduces that stage's bucket).  A no-op when nothing is pending. */
-int dali_resnet_join_grads(dali_resnet* net, void* stream);
+
 int dali_resnet_debug_tensor(dali_resnet* net, const char* name, void** ptr, int64_t* bytes);
 
 /* ---- net plan: TransReID ViT + BN neck (make_models.build_transformer.forward, make_models.py:184-205) ----- *

@@ -1,6 +1,6 @@
 """Per-GEMM timing of one ViT-B/16 block's linear layers at configs[3] (batch 128 x 197 tokens = 25216 rows): the 4 forward GEMMs, the 4
 data gradients and the 4 weight gradients with the epilogues the plan gives them.  HIP-event time per launch (20 launches after 3 warm-ups).
-The kernel choice follows the library's environment switches (DALI_CONV_320, DALI_CONV_K64_MINK, ...), read once per process: run it once
+The kernel choice follows the library's environment switches (DALI_CONV_CFG, DALI_CONV_K64), read once per process: run it once
 per setting.  MD=path appends a markdown table."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """LayerNorm backward / forward alone at the ViT-B/16 shape (batch 128 x 197 tokens x 768), variants interleaved in ONE process:
-    python scripts/bench_ln.py "DALI_LN_WAVES=2 DALI_LN_BLOCKS=768" "DALI_LN_WAVES=3" ...
+    python scripts/bench_ln.py "" ...      (each argument: a space-separated list of NAME=VALUE switches, may be empty)
 GB/s = algorithmic bytes (g, x, [add] read + dx written, bf16) / time."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

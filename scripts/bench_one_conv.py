@@ -24,4 +24,4 @@ fl = 2.0 * B * ho * wo * cout * cin * k * k
 tf = timeit(lambda: nn.conv2d_fwd(x, w, st, pad, want_stats=True))
 td = timeit(lambda: nn.conv2d_dgrad(dy, wt, (H, W), st, pad))
 tw = timeit(lambda: nn.conv2d_wgrad(x, dy, (k, k), st, pad))
-print("%s env NP=%s: fwd %.1f us (%.0f TF/s)  dgrad %.1f us  wgrad %.1f us" % (sys.argv[1:7], os.environ.get("DALI_NARROW_NP", "-"), tf, fl / tf / 1e6, td, tw))
+print("%s env NP=%s: fwd %.1f us (%.0f TF/s)  dgrad %.1f us  wgrad %.1f us" % (sys.argv[1:7], "-", tf, fl / tf / 1e6, td, tw))

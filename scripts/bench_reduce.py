@@ -1,5 +1,5 @@
-"""The split-K reduce alone at the slab shapes of the ResNet-50-ReID weight gradients (batch 256), wave counts interleaved in ONE process:
-    python scripts/bench_reduce.py [--reps 5] [W ...]         (W = values of DALI_REDUCE_WAVES; 0 = the shipped rule)
+"""The split-K reduce alone at the slab shapes of the ResNet-50-ReID weight gradients (batch 256):
+    python scripts/bench_reduce.py [--reps 5]
 The slabs are rewritten by a fill kernel before every timed launch (as the weight-gradient kernel leaves them: freshly written, not read),
 each launch is timed by its own pair of events.  GB/s = (splits + 1) x elems x 4 bytes / time."""
 import sys, os, ctypes
@@ -37,7 +37,6 @@ for name, H, W, cin, cout, k, st, cnt in L:
     st_ptr = torch.cuda.current_stream().cuda_stream
     for r in range(reps):
         for i, w in enumerate(waves):
-            os.environ["DALI_REDUCE_WAVES"] = str(w); lib.dali_debug_reload_env()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             slabs.fill_(1.0)
             e0.record()

@@ -1,5 +1,5 @@
 """ViT-B/16 linear weight gradients at batch 128 (25216 rows), with and without the bias gradient riding on the GEMM, variants interleaved in ONE process:
-    python scripts/bench_vit_wgrad.py "DALI_WGRAD_SPEC_TILES=40" "DALI_WGRAD_SPEC_TILES=100" ..."""
+    python scripts/bench_vit_wgrad.py "DALI_WGRAD_CFG=0" "" ..."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,5 @@
 """Weight-gradient launches (incl. the split-K reduce) at the ResNet-50-ReID shapes, per layer, variants interleaved in ONE process:
-    python scripts/bench_wgrad.py "DALI_WGRAD_P=0" "DALI_WGRAD_P=1" ... [--filter l4] [--reps 5]
+    python scripts/bench_wgrad.py "DALI_WGRAD_CFG=0" "" ... [--filter l4] [--reps 5]
 Each variant is a space-separated list of NAME=VALUE switches (re-read through dali_debug_reload_env)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
