@@ -229,7 +229,7 @@ def committed_traffic(which, key="gemm_kernels_hbm_bytes_per_step"):
     """HBM bytes per step of the GEMM kernels from the committed PMC pass (profiles/*_pmc_traffic.json: rocprofv3 --pmc in
     its own run, corrected as MI355X_MICROARCH.md prescribes).  -> (bytes or None, provenance string).  The number is NOT
     measured in this run; it is reported only while the kernel sources still hash to what the profile was taken on."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, which))
         try:
             with open(path) as f:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_<wl>/ (from scripts/profile_train.sh) -> profiles/<ROUND>_<wl>_* (committed summary)."""
 import csv, json, os, shutil, sys
-RND = os.environ.get("ROUND", "r03")
+RND = os.environ.get("ROUND", "r04")
 wl = sys.argv[1] if len(sys.argv) > 1 else "train"
 src, name = "gpurun_out/prof_%s" % wl, {"train": "train_step", "vit": "vit_step"}[wl]
 shutil.copy(src + "/pmc_traffic.json", "profiles/%s_%s_pmc_traffic.json" % (RND, wl))
@@ -15,15 +15,12 @@ steps = 16
 out = ["# Round %s -- %s kernel profile\n" % (RND[1:].lstrip("0"), name.replace("_", " "))]
 out.append("Produced by `bash scripts/profile_train.sh %s` on an MI355X box: (1) plain `python bench.py --workload %s --steps 10 --warmup 3`, "
            "(2) `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload %s --steps 10 --warmup 3 --no-cpu-baseline`, "
-           "(3)+(4) `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run, `-- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-distance` "
-           "(passes 2-4 run with `--no-distance`; pass 1 is the driver's default command); "
+           "(3)+(4) `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run, `-- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-distance --no-vit --no-epoch` "
+           "(passes 2-5 profile the train step alone; pass 1 is the driver's default command, with the distance / vit / epoch sub-records); "
            "summary by `scripts/make_profile_md.py`.\n" % (wl, wl, wl))
 out.append("Bench line of run (1) (unprofiled):\n\n```\n%s\n```\n" % bench_full)
 out.append("Bench line of run (2) (under rocprofv3):\n\n```\n%s\n```\n" % bench)
 out.append("## Per-kernel summary of run (2) (%d steps in the process: 3 warm-up + 10 timed + 3 event-bracketed)\n" % steps)
-out.append("Note (round 3): up to round 2 this table showed the split-K reduce at 21-33 us per launch and a note here blamed rocprofv3's attribution "
-           "(the micro-benchmark of the reduce measured 1-6 us).  The profile was right: the library kernel carried a scalar path the micro-benchmark "
-           "lacked, which made every wave read the dispatch packet (DESIGN.md section 6); fixed in round 3.\n")
 out.append("| kernel | calls | total ms | ms/step | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|---:|")
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
 for r in rows[:40]:
