@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void bnlin_finish_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bnlin_row_kernel(const uint16_t* __restrict__ W, const float* __restrict__ Ut, const float* __restrict__ m2,
                                                          const float* __restrict__ s_dz, int C, int w, double count, const float* __restrict__ scale,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dW,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, uint16_t* __restrict__ wd1,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, uint16_t* __restrict__ wd1, int ld1,
                                                          float* __restrict__ qk) {
     extern __shared__ __attribute__((aligned(16))) float bl_smem[];
     float* wf = bl_smem;                                    // [BL_CH][w]
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const uint16_t* __restri
         uint32_t o[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[t] = pack_bf16x2(coef[2 * t][0] * wf[(2 * t) * w + k], coef[2 * t + 1][0] * wf[(2 * t + 1) * w + k]);
-        *reinterpret_cast<uint4*>(wd1 + (size_t)k * C + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(wd1 + (size_t)k * ld1 + c0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -242,13 +242,15 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
 
 int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
-                     uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk) {
+                     uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk, int ld1, int ld2) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
+    if (ld1 <= 0) ld1 = C;
+    if (ld2 <= 0) ld2 = w;
     hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, W, ut, m2, s_dz, C, w,
-                       count, scale, mean, invstd, dW, dgamma, dbeta, wd1, qk);
+                       count, scale, mean, invstd, dW, dgamma, dbeta, wd1, ld1, qk);
     DALI_LAUNCH_CHECK();
     // wd2 = -(W^T diag(Q) W) [w][w] (bf16), bvec = W^T Kc: A = B = W [K = C][w], scaled by Q along K; v = Kc
-    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<uint16_t, true, true>), dim3(w / 32, w / 32), dim3(256), 0, st, W, w, W, w, qk, C, (float*)nullptr, wd2, w,
+    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<uint16_t, true, true>), dim3(w / 32, w / 32), dim3(256), 0, st, W, w, W, w, qk, C, (float*)nullptr, wd2, ld2,
                        (const uint16_t*)nullptr, 0, (float*)nullptr, 0, qk + C, bvec);
     DALI_LAUNCH_CHECK();
     return DALI_OK;

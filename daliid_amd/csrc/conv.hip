@@ -777,7 +777,9 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(IGemmArgs a, int tiles_
 // ------------------------------------------------------------------------------------------------
 // (lds_void_ptr, DMA_OOB, dma_wait<N> live in gemm_tile.h: shared with eval.hip)
 
-template <int TM, int TN, int NSTAGE, int EPI = 0>        // EPI: 0 convolution, 1 linear-layer extras, 3 fused output stage (conv_epilogue_g)
+// SRC2: K = the channels of X followed by the channels of a second plain [P][channels] tensor X2 (IGemmArgs::X2 / Ck1; 1x1, stride 1): its own
+// instantiations, so that the hot ones carry none of it.
+template <int TM, int TN, int NSTAGE, int EPI = 0, bool SRC2 = false>        // EPI: 0 convolution, 1 linear-layer extras, 3 fused output stage (conv_epilogue_g)
 __global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void igemm_conv_dma_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     // 128 x 128: <= 128 VGPRs (4 waves per SIMD); the 64 x 256 shape carries twice the per-lane gather state and would spill
     using Cfg = GemmCfg<TM, TN, 1, 1, 1>;
@@ -795,8 +797,10 @@ __global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void ige
     const int ktiles = (g.nr * g.ns * g.Ck) >> 5;      // taps actually visited (all of them unless g.sub)
 
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
-    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const long long x_bytes = SRC2 ? (long long)a.P * a.Ck1 * 2 : (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+    const int Ck2 = g.Ck - a.Ck1;                                   // (SRC2) channels of the second tensor
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SRC2 ? a.X2 : a.X), 0, SRC2 ? (int)((long long)a.P * Ck2 * 2) : (int)x_bytes, 0x00020000);
 
     // lane-constant part of the source swizzle: LDS slot `lane` of a block = row lane>>2, physical chunk lane&3
     const int r_in = lane >> 2;
@@ -821,6 +825,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void ige
         else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
         if (!ok) b_h0[i] = -0x40000000;                             // never in range
         b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;      // element offset of the image (+ this lane's chunk)
+        if constexpr (SRC2) b_pix[i] = ok ? p : -1;                  // plain rows: the pixel index itself (row pitch differs between the two tensors)
     }
 
     // wave-uniform k position
@@ -834,6 +839,19 @@ __global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void ige
         for (int i = 0; i < A_BLK; ++i) {
             const uint32_t off = (a_off[i] == DMA_OOB) ? DMA_OOB : a_off[i] + (uint32_t)kbase;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (wave + 4 * i) * 512), 16, off, 0, 0, 0);
+        }
+        if constexpr (SRC2) {
+            // K position kc0 lies in X (< Ck1) or in X2: a wave-uniform choice per k-tile
+            const bool second = kc0 >= a.Ck1;
+            const int pitch = second ? Ck2 : a.Ck1, cbase = (second ? kc0 - a.Ck1 : kc0) + kc * 8;
+#pragma unroll
+            for (int i = 0; i < B_BLK; ++i) {
+                const uint32_t off = b_pix[i] >= 0 ? (uint32_t)(b_pix[i] * pitch + cbase) * 2u : DMA_OOB;
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void_ptr)(sb + (wave + 4 * i) * 512), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + 4 * i) * 512), 16, off, 0, 0, 0);
+            }
+            kc0 += 32;
+            return;
         }
 #pragma unroll
         for (int i = 0; i < B_BLK; ++i) {
@@ -2633,7 +2651,17 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     // -18..-26 % on the 3x3 layers, -10 % on the K = 1024 1x1 layers; K = 512 layers +12..+20 % with either k-tile-64 kernel)
     const bool lin = a.act != 0 || a.O2 != nullptr || a.dact_pre != nullptr || a.row_scale != nullptr;      // linear-layer epilogue extras: the LIN kernel instantiations
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
-    const int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
+    int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
+    if (a.X2) {                                         // two operand tensors (IGemmArgs::X2): the SRC2 instantiations of the 128 x 128 / 64 x 256 LDS-DMA kernel
+        const bool fo = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;
+        if (in_bn || !dma_ok || a.stats || fo || lin || a.g.sub || a.g.R != 1 || a.g.S != 1 || a.g.stride != 1 || a.g.pad != 0 || a.Ck1 <= 0 || a.Ck1 >= a.g.Ck ||
+            (a.Ck1 & 31) || ((a.g.Ck - a.Ck1) & 31) || (a.Cm & 7)) {
+            set_error("conv: a second operand tensor needs a plain 1x1 / stride 1 problem with both channel counts multiples of 32");
+            return DALI_ERR_INVALID;
+        }
+        k64 = 0; narrow_k64 = 0;
+        if (!narrow) cfg = CONV_128;
+    }
     if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !((K >= 1024 && (cfg == CONV_256x256 || cfg == CONV_128x256)) || (K >= 768 && cfg == CONV_256x256))) k64 = 0;
     // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
     // instantiations compile none of it (code that is never executed still cost their register allocation 0.4-0.8 ms per step)
@@ -2737,6 +2765,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<64, 256, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok && a.X2) hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256, 3, 0, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<64, 256, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
     } else if (!in_bn && dma_ok && cfg == CONV_256x256) {
@@ -2764,6 +2793,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<128, 128, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else if (dma_ok && conv_cfg_override() == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
+        else if (dma_ok && a.X2) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 0, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else if (dma_ok && lin) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);

@@ -54,6 +54,12 @@ struct IGemmArgs {
     int out_relu;
     uint8_t* bits_out;        // 1 bit per output element, bit e & 7 of byte e >> 3, e = p*Cm + c (the layout of res_mask)
     const uint8_t* out_mask;  // same layout
+    // ---- second operand tensor (the SRC2 instantiations of igemm_conv_dma_kernel; 1x1 / stride 1 only) ----
+    // The GEMM's K dimension is the concatenation of X's Ck1 channels and X2's g.Ck - Ck1 channels, both [P][channels] bf16 (plain rows):
+    // O = [X | X2] W^T with W [Cm][g.Ck].  Two chained data gradients that accumulate into the same output (bnlin.hip: dz (A.W3) and
+    // -a2 (W3^T diag(Q) W3)) become one launch and the partial result is never stored.
+    const uint16_t* X2;
+    int Ck1;
 };
 
 struct WGradArgs {
@@ -108,9 +114,10 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
                        const float* beta, float* rm, float* rv, float momentum, float eps, float* ut, float* dot, float* scale, float* shift,
                        float* mean, float* invstd);
 // dW holds G0 = dz^T a (the reduced weight-gradient GEMM) on entry and the weight gradient on return; s_dz = colsum(dz) [C]
+// ld1 / ld2: row pitch (elements) of wd1 / wd2 (the net plan writes both into one [w][C + w] image: ld1 = ld2 = C + w, wd2 = wd1 + C)
 int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
-                     uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk);
+                     uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk, int ld1 = 0, int ld2 = 0);
 
 // nnops.hip
 constexpr int REDUCE_SMAX = 64;        // rows of the fp64 second-level scratch

@@ -45,7 +45,7 @@ struct Block {
     bool lin3 = false;
     float *gram = nullptr, *m2 = nullptr, *sdz = nullptr, *bvec = nullptr, *qk = nullptr;      // [w][w], [w], [cout], [w], [2][cout]
     float *ut = nullptr, *dot = nullptr;                       // (W3 gram)^T [w][cout] (forward -> backward), [w/32][cout] scratch
-    uint16_t *wd1 = nullptr, *wd2 = nullptr;                   // data-gradient images (A.W3)^T [w][cout] and -(W3^T diag(Q) W3) [w][w]
+    uint16_t* wd1 = nullptr;                                   // data-gradient image [w][cout + w]: (A.W3)^T beside -(W3^T diag(Q) W3)
 };
 
 struct Arena {
@@ -252,7 +252,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
         else {
             reserve(net, a, b.gram, (size_t)b.width * b.width * 4); reserve(net, a, b.m2, (size_t)b.width * 4);
             reserve(net, a, b.sdz, (size_t)b.cout * 4); reserve(net, a, b.bvec, (size_t)b.width * 4); reserve(net, a, b.qk, (size_t)b.cout * 8);
-            reserve(net, a, b.wd2, (size_t)b.width * b.width * 2); reserve(net, a, b.wd1, (size_t)b.width * b.cout * 2);
+            reserve(net, a, b.wd1, (size_t)b.width * (b.cout + b.width) * 2);          // [w][cout + w]: (A.W3)^T | -(W3^T diag(Q) W3), one data-gradient image
             reserve(net, a, b.ut, (size_t)b.width * b.cout * 4); reserve(net, a, b.dot, (size_t)(b.width / 32) * b.cout * 4);
             max_cs = std::max(max_cs, std::max(colsum_partial_floats((int)pout, b.cout), colsum_partial_floats((int)pout, b.width)) * 4);
             int sp, pps; size_t wsb;
@@ -528,13 +528,21 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
         if ((rc = launch_igemm_wgrad(st, wa, net->G + b.c3.w_off, 0, fused_cs ? b.sdz : nullptr,
                                      fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;           // G0 = dz^T a2 into the gradient slot; finished in place below
         if (!fused_cs && (rc = launch_colsum(st, dz, Pout, b.cout, b.sdz, net->cs_partial, net->red_scratch))) return rc;
+        const int ldw = b.cout + b.width;
         if ((rc = launch_bnlin_bwd(st, b.c3.w_bf16, b.ut, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
-                                   b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.wd1, b.wd2, b.bvec, b.qk))) return rc;
+                                   b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.wd1, b.wd1 + b.cout, b.bvec, b.qk, ldw, ldw))) return rc;
         d_a2 = next_gbuf(net, dz);
         scratch_a = next_gbuf(net, dz, d_a2);
-        if ((rc = conv_dgrad(net, st, b.c3, dz, nullptr, d_a2, nullptr, b.wd1, b.bvec))) return rc;             // dz (A.W3) + W3^T Kc
-        const Conv sq = square_conv(b.c3);
-        if ((rc = conv_dgrad(net, st, sq, b.a2, d_a2, d_a2, nullptr, b.wd2, nullptr))) return rc;               // - a2 (W3^T diag(Q) W3), in place
+        {   // d_a2 = dz (A.W3) + W3^T Kc - a2 (W3^T diag(Q) W3) as ONE GEMM over K = cout + w: [dz | a2] against the concatenated image
+            // (two launches with the partial result stored and re-read before: 190 -> see docs/experiments.md)
+            Conv cat = b.c3;
+            cat.cout = ldw;
+            IGemmArgs ga{};
+            ga.W = b.wd1; ga.X = dz; ga.X2 = b.a2; ga.Ck1 = b.cout; ga.O = d_a2; ga.bias = b.bvec;
+            ga.Cm = b.width; ga.P = Pout;
+            ga.g = conv_geom(cat, 1);
+            if ((rc = launch_igemm_conv(st, ga))) return rc;
+        }
         if (b.has_ds) {                                           // the downsample BatchNorm: its own two passes over (dz, rawd)
             d_rawd = next_gbuf(net, dz, d_a2, scratch_a);
             BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
