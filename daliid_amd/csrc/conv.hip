@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void igemm_conv_wg_kernel(IGemmArg
 // logical chunk ^ ((row >> 1) & 7): every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ... = 8 rows of one
 // chunk + 8 rows of the next) lands on 16 distinct 16-byte bank slots.  Needs Ck % 64 == 0.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4, int EPI = 0>
+template <int WM, int WN, int NSTAGE, int FM = 4, int FN = 4, int EPI = 0, bool SRC2 = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NW = WM * WN, NT = NW * 64;     // per-wave sub-tile 16 FM x 16 FN
     constexpr int A_BLK = TM / 8 / NW, B_BLK = (TN / 8 + NW - 1) / NW, NDMA = A_BLK + B_BLK;
@@ -1089,8 +1089,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
     const int K = g.R * g.S * g.Ck;                    // weight row length
     const int ktiles = (g.nr * g.ns * g.Ck) >> 6;      // taps actually visited (all of them unless g.sub)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
-    const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+    const long long x_bytes = SRC2 ? (long long)a.P * a.Ck1 * 2 : (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+    const int Ck2 = g.Ck - a.Ck1;                                   // (SRC2) channels of the second tensor
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SRC2 ? a.X2 : a.X), 0, SRC2 ? (int)((long long)a.P * Ck2 * 2) : (int)x_bytes, 0x00020000);
     // LDS slot `lane` of piece q (rows 8q .. 8q+7) = row 8q + (lane >> 3), physical chunk lane & 7; q = wave + NW * i has the
     // parity of the wave, so the logical chunk this lane fetches is the same for all of its pieces
     const int r_in = lane >> 3;
@@ -1113,6 +1115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
         else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
         if (!ok) b_h0[i] = -0x40000000;
         b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;
+        if constexpr (SRC2) b_pix[i] = ok ? p : -1;                  // plain rows: the pixel index itself
     }
     int kr = g.r0, ks = g.s0, kc0 = 0;
     const int ks_end = g.s0 + g.sstep * g.ns, kr_end = g.r0 + g.rstep * g.nr;
@@ -1124,6 +1127,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
         for (int i = 0; i < A_BLK; ++i) {
             const uint32_t off = (a_off[i] == DMA_OOB) ? DMA_OOB : a_off[i] + (uint32_t)kbase;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (wave + NW * i) * 512), 16, off, 0, 0, 0);
+        }
+        if constexpr (SRC2) {                             // K position kc0 lies in X (< Ck1) or in X2: a wave-uniform choice per k-tile
+            const bool second = kc0 >= a.Ck1;
+            const int pitch = second ? Ck2 : a.Ck1, cbase = (second ? kc0 - a.Ck1 : kc0) + kc * 8;
+#pragma unroll
+            for (int i = 0; i < B_BLK; ++i) {
+                const uint32_t off = b_pix[i] >= 0 ? (uint32_t)(b_pix[i] * pitch + cbase) * 2u : DMA_OOB;
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void_ptr)(sb + (wave + NW * i) * 512), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (wave + NW * i) * 512), 16, off, 0, 0, 0);
+            }
+            kc0 += 64;
+            return;
         }
 #pragma unroll
         for (int i = 0; i < B_BLK; ++i) {
@@ -1200,7 +1215,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
 // costs the issuing wave 60-185 cycles in which it cannot issue MFMAs, and the feed time added to the MFMA time instead of
 // hiding under it (ablations in scripts/ablate_conv.py, same finding and same cure as pairdist_dma_kernel in eval.hip).
 // The producers leave after the last k-step; the epilogue's barriers then count the consumers only.
-template <int WM, int WN, int NP, int NSTAGE, int FM = 4, int FN = 4, bool LIN = false>
+template <int WM, int WN, int NP, int NSTAGE, int FM = 4, int FN = 4, bool LIN = false, bool SRC2 = false>
 __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NC = WM * WN, NT = NC * 64;       // consumer sub-tile 16 FM x 16 FN
     constexpr int A_BLK = TM / 8 / NP, B_BLK = TN / 8 / NP, NDMA = A_BLK + B_BLK;
@@ -1220,8 +1235,10 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
         const int pw = wave - NC;
         const int K = g.R * g.S * g.Ck;                // weight row length
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, a.Cm * K * 2, 0x00020000);
-        const long long x_bytes = (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
+        const long long x_bytes = SRC2 ? (long long)a.P * a.Ck1 * 2 : (long long)g.img_pitch * 2 * ((a.P + g.Hout * g.Wout - 1) / (g.Hout * g.Wout));
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)x_bytes, 0x00020000);
+        const int Ck2 = g.Ck - a.Ck1;                                   // (SRC2) channels of the second tensor
+        const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SRC2 ? a.X2 : a.X), 0, SRC2 ? (int)((long long)a.P * Ck2 * 2) : (int)x_bytes, 0x00020000);
         const int r_in = lane >> 3;
         const int kc = (lane & 7) ^ (((pw & 1) << 2) | (r_in >> 1));      // see igemm_conv_k64_kernel
         uint32_t a_off[A_BLK];
@@ -1242,6 +1259,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
             else { b_h0[i] = ho + g.pad; b_w0[i] = wo + g.pad; }
             if (!ok) b_h0[i] = -0x40000000;
             b_pix[i] = (int)((long long)n * g.img_pitch) + kc * 8;
+            if constexpr (SRC2) b_pix[i] = ok ? p : -1;                  // plain rows: the pixel index itself
         }
         int kr = g.r0, ks = g.s0, kc0 = 0;
         const int ks_end = g.s0 + g.sstep * g.ns, kr_end = g.r0 + g.rstep * g.nr;
@@ -1253,6 +1271,18 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
             for (int i = 0; i < A_BLK; ++i) {
                 const uint32_t off = (a_off[i] == DMA_OOB) ? DMA_OOB : a_off[i] + (uint32_t)kbase;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (pw + NP * i) * 512), 16, off, 0, 0, 0);
+            }
+            if constexpr (SRC2) {                             // K position kc0 lies in X (< Ck1) or in X2: a wave-uniform choice per k-tile
+                const bool second = kc0 >= a.Ck1;
+                const int pitch = second ? Ck2 : a.Ck1, cbase = (second ? kc0 - a.Ck1 : kc0) + kc * 8;
+#pragma unroll
+                for (int i = 0; i < B_BLK; ++i) {
+                    const uint32_t off = b_pix[i] >= 0 ? (uint32_t)(b_pix[i] * pitch + cbase) * 2u : DMA_OOB;
+                    if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void_ptr)(sb + (pw + NP * i) * 512), 16, off, 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (pw + NP * i) * 512), 16, off, 0, 0, 0);
+                }
+                kc0 += 64;
+                return;
             }
 #pragma unroll
             for (int i = 0; i < B_BLK; ++i) {
@@ -2659,8 +2689,9 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             set_error("conv: a second operand tensor needs a plain 1x1 / stride 1 problem with both channel counts multiples of 32");
             return DALI_ERR_INVALID;
         }
-        k64 = 0; narrow_k64 = 0;
-        if (!narrow) cfg = CONV_128;
+        narrow_k64 = 0;
+        if ((a.Ck1 & 63) || ((a.g.Ck - a.Ck1) & 63)) k64 = 0;
+        if (!(k64 && (cfg == CONV_256x256 || cfg == CONV_128x256)) && !narrow) { cfg = CONV_128; k64 = 0; }
     }
     if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !((K >= 1024 && (cfg == CONV_256x256 || cfg == CONV_128x256)) || (K >= 768 && cfg == CONV_256x256))) k64 = 0;
     // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
@@ -2722,7 +2753,10 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         });
-        if (lin) hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        if (a.X2) {
+            DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+            hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 0, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        } else if (lin) hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128x256) {
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
@@ -2732,7 +2766,10 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         });
-        if (k64 == 6) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
+        if (a.X2) {
+            DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+            hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, false, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        } else if (k64 == 6) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
         else if (lin) hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128) {

@@ -146,11 +146,12 @@ GatherGeom conv_geom(const Conv& c, int mode) {
     return g;
 }
 // bn3 behind conv3 through the moments of conv3's input (bnlin.hip).  The scheme trades passes over [P][4w] tensors for products of size
-// w^2: it pays where P is large against w (layer1 / layer2 at batch 256: 0.5 / 0.13 M pixels against w = 64 / 128; measured per limit in
-// DESIGN.md).  DALI_BNLIN_MAXW moves the limit (0: every block keeps the materialised form).
+// w^2 and ~7 small launches per block.  Until round 4 it paid for w <= 128 only (layer1 / layer2); with the block's two data-gradient GEMMs
+// merged into one launch over [dz | a2] (IGemmArgs::X2) it pays for every block of ResNet-50 at batch 256: 15.71 (w <= 128) / 15.61 (<= 256) /
+// 15.47 ms (all), same box.  DALI_BNLIN_MAXW moves the limit (0: every block keeps the materialised form).
 int bnlin_max_width() {
     static int v = -1;
-    if (v == -1) { const char* e = getenv("DALI_BNLIN_MAXW"); v = e ? atoi(e) : 128; }
+    if (v == -1) { const char* e = getenv("DALI_BNLIN_MAXW"); v = e ? atoi(e) : 512; }
     return v;
 }
 // a cin = cout = w 1x1 convolution on the grid of conv3: the shape of the Gram GEMM a2^T a2 and of the second data-gradient GEMM

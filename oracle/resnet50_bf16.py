@@ -60,12 +60,10 @@ def _bn_train(u, uq, bn, eps=1e-5):
 
 def stores_raw3(blk):
     """Does the HIP plan store conv3's output of this bottleneck in bf16?  Not where bn3 runs through the moments of a2 (csrc/bnlin.hip):
-    blocks whose width is a multiple of 32 and at most DALI_BNLIN_MAXW (default 128; resnet_plan.hip)."""
+    blocks whose width is a multiple of 32 and at most DALI_BNLIN_MAXW (default 512 = every block of ResNet-50; resnet_plan.hip)."""
     import os
-    if os.environ.get("DALI_BNLIN", "1") == "0" or (blk.downsample is not None and os.environ.get("DALI_BNLIN_DS", "1") == "0"):
-        return True
     w = blk.conv3.in_channels
-    return not (w % 32 == 0 and w <= int(os.environ.get("DALI_BNLIN_MAXW", "128")))
+    return not (w % 32 == 0 and w <= int(os.environ.get("DALI_BNLIN_MAXW", "512")))
 
 
 def _conv(x, conv):
