@@ -3148,6 +3148,18 @@ extern "C" int dali_conv1x1_fused(dali_ctx* ctx, void* stream, const uint16_t* x
     return launch_igemm_conv((hipStream_t)stream, a);
 }
 
+// y [pixels][cout] = [x1 | x2] @ w^T (+ bias): one GEMM whose K dimension is the concatenation of two plain [pixels][c] tensors (IGemmArgs::X2)
+extern "C" int dali_conv1x1_cat(dali_ctx* ctx, void* stream, const uint16_t* x1, int c1, const uint16_t* x2, int c2, const uint16_t* w, const float* bias,
+                                uint16_t* y, int pixels, int cout) {
+    DALI_REQUIRE(ctx && x1 && x2 && w && y, "dali_conv1x1_cat: null argument");
+    DALI_REQUIRE(c1 > 0 && c2 > 0 && c1 % 32 == 0 && c2 % 32 == 0 && cout % 8 == 0 && pixels > 0, "dali_conv1x1_cat: c1 %% 32, c2 %% 32, cout %% 8 (c1=%d c2=%d cout=%d)", c1, c2, cout);
+    IGemmArgs a{};
+    a.W = w; a.X = x1; a.X2 = x2; a.Ck1 = c1; a.O = y; a.bias = bias;
+    a.Cm = cout; a.P = pixels;
+    fill_geom(a.g, 1, 1, pixels, c1 + c2, 1, pixels, 1, 1, 1, 0, 0);
+    return launch_igemm_conv((hipStream_t)stream, a);
+}
+
 static void linear_geom(GatherGeom& g, int K) {
     g.Hout = 1; g.Wout = 1; g.Hin = 1; g.Win = 1; g.Ck = K; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.mode = 0;
     g.pix_pitch = K; g.row_pitch = K; g.img_pitch = K; g.lw = g.lhw = -1;

@@ -74,6 +74,18 @@ def conv1x1_fused(x, w, out_scale=None, out_shift=None, bias=None, residual=None
     return (y, bits) if want_bits else y
 
 
+def conv1x1_cat(x1, x2, w, bias=None):
+    """x1 [P,c1], x2 [P,c2] bf16, w [cout, c1 + c2] bf16 -> y [P,cout] = [x1 | x2] @ w.T (+ bias): one GEMM over two operand tensors."""
+    P, c1 = x1.shape
+    c2 = x2.shape[1]
+    cout = w.shape[0]
+    assert x2.shape[0] == P and w.shape[1] == c1 + c2
+    y = torch.empty(P, cout, device=x1.device, dtype=bf16)
+    _lib.check(_lib.lib().dali_conv1x1_cat(_lib.ctx(x1.device), _lib.stream_ptr(), _lib.ptr(x1, bf16, "x1"), c1, _lib.ptr(x2, bf16, "x2"), c2,
+                                            _lib.ptr(w, bf16, "w"), _lib.ptr(bias), _lib.ptr(y), P, cout), "dali_conv1x1_cat")
+    return y
+
+
 def bnlin_fwd(a, w, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """a [P,w] bf16, w [C,w] bf16 -> dict(gram, m2, scale, shift, mean, invstd): training-mode BatchNorm coefficients of a @ w.T"""
     P, wd = a.shape

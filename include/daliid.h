@@ -150,6 +150,12 @@ int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16
 int dali_conv1x1_fused(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y, int pixels, int cin, int cout,
                        const float* out_scale, const float* out_shift, const float* bias, const uint16_t* residual, int out_relu,
                        uint8_t* bits_out, const uint8_t* out_mask, const float* res_scale);
+/* y [pixels][cout] = [x1 | x2] @ w^T (+ bias): a 1x1 GEMM whose reduction runs over the c1 channels of x1 followed by the c2 channels of a SECOND
+ * tensor x2 (both plain [pixels][c] bf16; w [cout][c1 + c2]).  Two chained data gradients that accumulate into one output become one launch and the
+ * partial result is never stored: the conv3 backward of a Gram-scheme bottleneck, d_a2 = dz (A.W3) + W3^T Kc - a2 (W3^T diag(Q) W3)
+ * (autograd of torchvision's Bottleneck tail under Encoders.py:330-339).  c1 % 32 == 0, c2 % 32 == 0, cout % 8 == 0; bias nullable. */
+int dali_conv1x1_cat(dali_ctx* ctx, void* stream, const uint16_t* x1, int c1, const uint16_t* x2, int c2, const uint16_t* w, const float* bias,
+                     uint16_t* y, int pixels, int cout);
 /* Training-mode BatchNorm behind a 1x1 convolution WITHOUT the convolution's output (csrc/bnlin.hip): raw = a W^T is linear in
  * a [P][w] (bf16), so its batch statistics follow from gram = a^T a [w][w] and m2 = colsum(a) [w] (returned, fp32):
  * mean = W m2 / P, E[raw^2] = diag(W gram W^T) / P; ut = (W gram)^T [w][C] (fp32) is returned for the backward, with m2.  Outputs scale = gamma*invstd, shift = beta - mean*scale,

@@ -157,3 +157,23 @@ def test_splitk_reduce_alone(nn, elems, splits, accumulate):
     ref = slabs.double().sum(0) + (before[:elems].double() if accumulate else 0)
     assert torch.equal(out[:elems].double(), ref)
     assert torch.equal(out[elems:], before[elems:])
+
+
+# (pixels, c1, c2, cout): the kernels with a second operand tensor (IGemmArgs::X2, the SRC2 instantiations) -- 64 x 256 and 128 x 128 LDS-DMA,
+# wave-specialised 128 x 256 k-tile 64 (K >= 1024, cout 128..256, P >= 16384), 256 x 256 k-tile 64 (cout >= 512); ragged pixel counts included
+@pytest.mark.parametrize("P,c1,c2,cout", [(777, 256, 64, 64), (1000, 512, 128, 128), (300, 64, 32, 24), (16640, 1024, 256, 256), (16500, 2048, 512, 512),
+                                           (16384, 1024, 64, 128)])
+def test_conv1x1_two_operand_tensors_exact_integers(nn, P, c1, c2, cout):
+    """y = [x1 | x2] @ w^T + bias in ONE launch (dali_conv1x1_cat; the merged conv3 data gradient of the Gram-scheme blocks): small integers, so the
+    result must equal the fp32 oracle rounded once to bf16 bit for bit."""
+    g = torch.Generator().manual_seed(P + c1 + cout)
+    x1 = torch.randint(-2, 3, (P, c1), generator=g).float()
+    x2 = torch.randint(-2, 3, (P, c2), generator=g).float()
+    w = torch.randint(-1, 2, (cout, c1 + c2), generator=g).float()
+    w[:, c1:] *= 2                                              # the second tensor's weights are distinguishable from the first's
+    bias = torch.randint(-3, 4, (cout,), generator=g).float()
+    ref = (torch.cat((x1, x2), 1) @ w.t() + bias).to(bf16)
+    y = nn.conv1x1_cat(x1.to(bf16).cuda(), x2.to(bf16).cuda(), w.to(bf16).cuda(), bias.cuda())
+    assert torch.equal(y.cpu(), ref), (y.cpu().float() - ref.float()).abs().max()
+    y0 = nn.conv1x1_cat(x1.to(bf16).cuda(), x2.to(bf16).cuda(), w.to(bf16).cuda())
+    assert torch.equal(y0.cpu(), (torch.cat((x1, x2), 1) @ w.t()).to(bf16))
