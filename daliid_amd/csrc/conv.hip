@@ -2858,6 +2858,7 @@ int wgrad_pick_cfg(int Cm, int Ntot, int taps, int P, int halo_w) {
     if (ov != 0 && taps == 9 && (halo_w == 8 || halo_w == 16 || halo_w == 32) && Cm % 64 == 0 && (Ntot / 9) % 64 == 0 && P % 32 == 0) return 3;
     if (ov == 2) return (Ntot >= 256) ? 2 : 0;
     if (ov >= 0) return (ov == 1 && Cm >= 256 && Ntot >= 256) ? 1 : 0;
+    if (taps == 7 && Ntot == 224 && P >= 16384) return 2;         // the stem (7 tap rows of 32): one 256-wide n tile, dY read once (187 -> ~155 us)
     return (taps == 1 && Ntot >= 256 && P >= 16384) ? 2 : 0;      // incl. the ViT linears (P = 25216)
 }
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps, int halo_w) {

@@ -240,7 +240,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
     size_t max_slab = 0, max_cs = 256;
     {
         int sp, pps; size_t wsb;
-        wgrad_plan(wb, 224, (int)N * net->stem_h * net->stem_w, 512, &sp, &pps, &wsb);
+        wgrad_plan(wb, 224, (int)N * net->stem_h * net->stem_w, 512, &sp, &pps, &wsb, 7);
         max_slab = wsb;
     }
     for (auto& b : net->blocks) {
@@ -626,7 +626,7 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
             a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w; a.Ntot = 224;
             a.g = stem_geom(net);
             size_t wsb;
-            wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb);
+            wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb, 7);
             if ((rc = launch_igemm_wgrad(st, a, net->stem_dw_pad, 0))) return rc;
             if ((rc = launch_stem_unpack_wgrad(st, net->stem_dw_pad, net->stem.cout, net->G + net->stem.w_off))) return rc;
         }
