@@ -418,7 +418,9 @@ def bench_train(args, world, rank):
                                "device_ms": round(gpu_ms, 3)},
                 "note": "achieved = algorithmic GEMM FLOPs per step (%.3f GFLOP/img x %d) / summed duration of the GEMM kernel launches of "
                         "one step, HIP events per launch on the launch stream; whole_step divides the same FLOPs by the device time of the "
-                        "entire step (BatchNorm, pools, heads, Adam, EMA included)" % (gflop_img, batch)}
+                        "entire step (BatchNorm, pools, heads, Adam, EMA included).  The GEMM launches also carry fused non-GEMM work (every bn3 + residual + ReLU + "
+                        "mask output stage, the Gram-scheme products and column sums: launched_gemm_tflop_per_step > the algorithmic figure), so moving "
+                        "work into them lowers `frac` while the step gets faster: read whole_step beside it" % (gflop_img, batch)}
     final = acc.cpu().numpy()
     log("GPU: %.3f ms/step (device %.3f ms), %.1f images/s" % (ms_step, gpu_ms, ips))
     comm = None
