@@ -196,3 +196,20 @@ def test_prefetch_overlaps_decode_with_gpu_work(T, tmp_path, monkeypatch):
     print("prefetched epoch %.3f s (serial decode alone %.2f s, GPU alone %.2f s)" % (t, t_seq_decode, t_gpu))
     assert t < 0.5 * (t_seq_decode + t_gpu)              # nowhere near the sum
     assert t < 2.5 * max(t_seq_decode / 8, t_gpu) + 0.15
+
+
+def test_extract_features_batched_path_equals_per_batch_loader_calls(T, tmp_path):
+    """getFeatures.extractFeatures with the batched loader protocol (batch i + 1 decoding on the pool while batch i's forward runs, resize +
+    normalise on a side stream) against the plain per-batch loader calls: identical features, in dataset order, ragged last batch included."""
+    from daliid_amd import Encoders, getFeatures
+    records, _ = _write_dataset(tmp_path, 5, 3, hw=(96, 40), turb=False, fmt="png")
+    net = Encoders._DataParallelShim(Encoders.ResNet50ReID(layers=(1, 1, 1, 1), width=32, seed=3)).eval()
+    try:
+        getFeatures.set_image_loader(T.gpu_eval_loader)
+        batched = getFeatures.extractFeatures(records, 64, 32, net, 4, gpu_index=0, verbose=False)          # 15 images: batches of 4, 4, 4, 3
+        plain = lambda paths, h, w, turb=None: T.gpu_eval_loader(paths, h, w, turb)                       # same pixels, no plan / submit / finish attributes
+        getFeatures.set_image_loader(plain)
+        sequential = getFeatures.extractFeatures(records, 64, 32, net, 4, gpu_index=0, verbose=False)
+    finally:
+        getFeatures.set_image_loader(None)
+    assert batched.shape == (15, 1024) and torch.equal(batched, sequential)
