@@ -628,7 +628,8 @@ def main():
             d = bench_distance(args, world, rank)
             d.pop("metric")
             res["distance"] = d
-        if args.workload == "train" and not args.no_vit:
+        # (the vit / epoch sub-records belong to the single-GPU line: the scaling runs time the train step and the distance leg only)
+        if args.workload == "train" and not args.no_vit and world == 1:
             # configs[3] in the driver's line as well: 5 warm-up + 20 timed ViT-B/16 steps (~0.6 s)
             torch.cuda.empty_cache()
             va = argparse.Namespace(**vars(args))
@@ -636,7 +637,7 @@ def main():
             v = bench_train(va, world, rank)
             v.pop("metric"); v["steps"], v["warmup"] = va.steps, va.warmup
             res["vit"] = v
-        if args.workload == "train" and not args.no_epoch:
+        if args.workload == "train" and not args.no_epoch and world == 1:
             torch.cuda.empty_cache()
             e = bench_epoch(args, world, rank)
             res["epoch"] = e
