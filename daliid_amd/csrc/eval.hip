@@ -24,6 +24,49 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict_
     const float* xr = x + (size_t)row * d;
     float ss = 0.f;
     const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec && Kp == d && d <= 2048 && !yout && img) {
+        // the whole row in registers (<= 8 float4 per lane): all loads in flight at once, one pass over memory.  Same arithmetic, in the same
+        // order, as the two-sweep form below (the squares are added chunk by chunk, lane sums by wave_sum).
+        float4 v4[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = lane * 4 + k * 256;
+            v4[k] = c < d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (lane * 4 + k * 256 < d) ss += v4[k].x * v4[k].x + v4[k].y * v4[k].y + v4[k].z * v4[k].z + v4[k].w * v4[k].w;
+        ss = wave_sum(ss);
+        const float nrm1 = sqrtf(ss);
+        const float den1 = normalize ? (nrm1 + eps) : 1.0f;
+        if (lane == 0) {
+            if (norms) norms[row] = nrm1;
+            if (sq) sq[row] = normalize ? (ss / (den1 * den1)) : ss;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = lane * 4 + k * 256;
+            if (c < d) {
+                const float v[4] = {v4[k].x / den1, v4[k].y / den1, v4[k].z / den1, v4[k].w / den1};
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    h[t] = f32_to_bf16_bits(v[t]);
+                    l[t] = f32_to_bf16_bits(v[t] - bf16_bits_to_f32(h[t]));
+                }
+                const uint2 hv = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                if (layout == 3) {
+                    uint16_t* dst = img + (size_t)row * (2 * Kp) + (c >> 5) * 64 + (c & 31);
+                    const uint2 lv = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                    *reinterpret_cast<uint2*>(dst) = hv;
+                    *reinterpret_cast<uint2*>(dst + 32) = lv;
+                } else {
+                    *reinterpret_cast<uint2*>(img + (size_t)row * Kp + c) = hv;
+                }
+            }
+        }
+        return;
+    }
     if (vec) {
         for (int c = lane * 4; c < d; c += 256) {
             const float4 v = *reinterpret_cast<const float4*>(xr + c);
