@@ -240,6 +240,15 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
     return DALI_OK;
 }
 
+// only Ut = (W G)^T [w][C] (a scheme whose forward statistics come from elsewhere: the downsample branch, resnet_plan.hip)
+int launch_bnlin_ut(hipStream_t st, const uint16_t* Wt, const float* gram, int C, int w, float* ut) {
+    if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
+    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<float, false, false>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, Wt, C, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
+                       (const uint16_t*)nullptr, 0, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+
 int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk, int ld1, int ld2) {

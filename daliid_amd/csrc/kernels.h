@@ -115,6 +115,7 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
                        float* mean, float* invstd);
 // dW holds G0 = dz^T a (the reduced weight-gradient GEMM) on entry and the weight gradient on return; s_dz = colsum(dz) [C]
 // ld1 / ld2: row pitch (elements) of wd1 / wd2 (the net plan writes both into one [w][C + w] image: ld1 = ld2 = C + w, wd2 = wd1 + C)
+int launch_bnlin_ut(hipStream_t st, const uint16_t* Wt, const float* gram, int C, int w, float* ut);
 int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk, int ld1 = 0, int ld2 = 0);

@@ -46,6 +46,11 @@ struct Block {
     float *gram = nullptr, *m2 = nullptr, *sdz = nullptr, *bvec = nullptr, *qk = nullptr;      // [w][w], [w], [cout], [w], [2][cout]
     float *ut = nullptr, *dot = nullptr;                       // (W3 gram)^T [w][cout] (forward -> backward), [w/32][cout] scratch
     uint16_t* wd1 = nullptr;                                   // data-gradient image [w][cout + w]: (A.W3)^T beside -(W3^T diag(Q) W3)
+    // the downsample BatchNorm's backward through the moments of the block input x (same scheme, backward only: rawd is still what the forward
+    // stores and conv3's epilogue reads): no reduce / apply passes over (dz, rawd), d_rawd is never formed
+    bool lin_ds = false;
+    float *gram_d = nullptr, *m2_d = nullptr, *ut_d = nullptr, *bvec_d = nullptr, *qk_d = nullptr;   // [cin][cin], [cin], [cin][cout], [cin], [2][cout]
+    uint16_t* wdd = nullptr;                                   // [cin][cout + cin]: (A_d.Wd)^T beside -(Wd^T diag(Q_d) Wd)
 };
 
 struct Arena {
@@ -214,6 +219,9 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             // bn3 through the moments of a2 (bnlin.hip); in a block with a downsample branch the identity enters conv3's epilogue as
             // scale_d * rawd + shift_d (res_scale / bias) and the downsample BatchNorm keeps its own two-pass backward
             b.lin3 = planes % 32 == 0 && planes <= bnlin_max_width();
+            // ... except where the branch is a stride-1 convolution of a narrow input (ResNet-50: layer1's, 64 -> 256 over 524288 pixels at batch
+            // 256), whose Gram matrix costs less than the two passes: there its backward goes through the moments of x as well (block_backward)
+            b.lin_ds = b.has_ds && b.lin3 && st == 1 && inpl % 32 == 0 && inpl <= 128 && net->blocks.empty();   // (first block of the net: no mask on dx)
             h = b.hout; w = b.wout; inpl = planes * 4;
             net->blocks.push_back(b);
         }
@@ -266,6 +274,15 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
         reserve(net, a, b.y, pout * b.cout * 2);
         reserve(net, a, b.ybits, pout * b.cout / 8);
         if (b.has_ds) reserve(net, a, b.rawd, pout * b.cout * 2);
+        if (b.lin_ds) {
+            reserve(net, a, b.gram_d, (size_t)b.cin * b.cin * 4); reserve(net, a, b.m2_d, (size_t)b.cin * 4);
+            reserve(net, a, b.ut_d, (size_t)b.cin * b.cout * 4); reserve(net, a, b.bvec_d, (size_t)b.cin * 4); reserve(net, a, b.qk_d, (size_t)b.cout * 8);
+            reserve(net, a, b.wdd, (size_t)b.cin * (b.cout + b.cin) * 2);
+            int sp, pps; size_t wsb;
+            wgrad_plan(b.cin, b.cin, (int)pin, 512, &sp, &pps, &wsb, 1, 0);
+            max_slab = std::max(max_slab, wsb);
+            max_cs = std::max(max_cs, std::max(colsum_partial_floats((int)pin, b.cin), (size_t)wgrad_colsum_rows(b.cin, b.cin, 1, (int)pin, sp) * b.cin) * 4);
+        }
         reserve_bn(net, a, b.b1); reserve_bn(net, a, b.b2); reserve_bn(net, a, b.b3);
         if (b.has_ds) reserve_bn(net, a, b.bd);
         Conv* cs[4] = {&b.c1, &b.c2, &b.c3, b.has_ds ? &b.cd : nullptr};
@@ -486,6 +503,20 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
             if (b.has_ds) {                               // identity = bnd(convd(x)): raw output + its BatchNorm as residual scale / extra shift
                 if ((rc = conv_bn_fwd(net, st, b.cd, b.bd, x, nullptr, b.rawd, tr))) return rc;
                 a.Res = b.rawd; a.res_scale = b.bd.scale; a.bias = b.bd.shift;
+                if (b.lin_ds && tr) {                         // moments of x for the branch's backward: G_x = x^T x, m2 = colsum(x), Ut = (Wd G_x)^T
+                    Conv sq = b.cd;
+                    sq.cout = b.cd.cin;
+                    WGradArgs wa{};
+                    wa.dY = x; wa.X = x; wa.partial = net->wgrad_slab; wa.Cm = b.cin; wa.P = Pout; wa.Ntot = b.cin;
+                    wa.g = conv_geom(sq, 0);
+                    size_t wsb;
+                    wgrad_plan(wa.Cm, wa.Ntot, wa.P, 512, &wa.splits, &wa.pix_per_split, &wsb, 1, 0);
+                    const bool fused_cs = wgrad_colsum_supported(wa.Cm, wa.Ntot, 1, wa.P);
+                    if (fused_cs) wa.colsum = net->cs_partial;
+                    if ((rc = launch_igemm_wgrad(st, wa, b.gram_d, 0, fused_cs ? b.m2_d : nullptr, fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;
+                    if (!fused_cs && (rc = launch_colsum(st, x, Pout, b.cin, b.m2_d, net->cs_partial, net->red_scratch))) return rc;
+                    if ((rc = launch_bnlin_ut(st, b.cd.wt_bf16, b.gram_d, b.cout, b.cin, b.ut_d))) return rc;
+                }
             }
             a.bits_out = tr ? b.ybits : nullptr;
             a.Cm = b.cout; a.P = Pout; a.g = conv_geom(b.c3, 0);
@@ -544,7 +575,19 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
             ga.g = conv_geom(cat, 1);
             if ((rc = launch_igemm_conv(st, ga))) return rc;
         }
-        if (b.has_ds) {                                           // the downsample BatchNorm: its own two passes over (dz, rawd)
+        if (b.lin_ds) {
+            // downsample branch through the moments of x: G0d = dz^T x into the gradient slot (s = colsum(dz) is bn3's), finished in place by the row
+            // kernel together with dgamma / dbeta and the two data-gradient images; the data gradient itself follows conv1's below
+            WGradArgs wd{};
+            wd.dY = dz; wd.X = b.x; wd.partial = net->wgrad_slab; wd.Cm = b.cout; wd.P = Pout; wd.Ntot = b.cin;
+            wd.g = conv_geom(b.cd, 0);
+            size_t wsb2;
+            wgrad_plan(wd.Cm, wd.Ntot, wd.P, 512, &wd.splits, &wd.pix_per_split, &wsb2, 1, 0);
+            if ((rc = launch_igemm_wgrad(st, wd, net->G + b.cd.w_off, 0))) return rc;
+            const int ldd = b.cout + b.cin;
+            if ((rc = launch_bnlin_bwd(st, b.cd.w_bf16, b.ut_d, b.m2_d, b.sdz, b.cout, b.cin, (double)Pout, b.bd.scale, b.bd.mean, b.bd.invstd,
+                                       net->G + b.cd.w_off, net->G + b.bd.g_off, net->G + b.bd.b_off, b.wdd, b.wdd + b.cout, b.bvec_d, b.qk_d, ldd, ldd))) return rc;
+        } else if (b.has_ds) {                                    // the downsample BatchNorm: its own two passes over (dz, rawd)
             d_rawd = next_gbuf(net, dz, d_a2, scratch_a);
             BnBwdSide sd{b.rawd, b.bd.mean, b.bd.invstd, b.bd.scale, b.bd.shift};
             if ((rc = launch_bn_bwd(st, dz, nullptr, nullptr, sd, nullptr, 0, Pout, b.cout, net->bwd_partial, b.bd.coef, nullptr, net->G + b.bd.g_off,
@@ -579,7 +622,17 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
     // conv1 (+ identity / downsample branch); the result is masked with the previous block's ReLU bits
     if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
     uint16_t* dx = d_a2;                                          // d_a2 is dead now
-    if (b.has_ds) {
+    if (b.lin_ds) {
+        // dx = d_a1 W1 + [dz | x] [(A_d.Wd)^T | -(Wd^T diag(Q_d) Wd)] + Wd^T Kc: conv1's data gradient, then the branch's two-operand GEMM on top of it
+        if ((rc = conv_dgrad(net, st, b.c1, d_a1, nullptr, dx, prev_bits))) return rc;
+        Conv cat = b.cd;
+        cat.cout = b.cout + b.cin;
+        IGemmArgs ga{};
+        ga.W = b.wdd; ga.X = dz; ga.X2 = b.x; ga.Ck1 = b.cout; ga.O = dx; ga.Res = dx; ga.bias = b.bvec_d;
+        ga.Cm = b.cin; ga.P = Pin;
+        ga.g = conv_geom(cat, 1);
+        if ((rc = launch_igemm_conv(st, ga))) return rc;
+    } else if (b.has_ds) {
         if ((rc = conv_wgrad(net, st, b.cd, b.x, nullptr, d_rawd))) return rc;
         // conv1's data gradient first, then the downsample branch accumulates into it in place: with stride 2 only the
         // even-even quarter of the positions receives a contribution (launch_igemm_conv's parity split).  (a + b) * m = a * m + b * m:

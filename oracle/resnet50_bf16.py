@@ -12,7 +12,8 @@ Rounding points mirrored (daliid_amd/csrc/resnet_plan.hip):
   images and conv weights -> bf16 operands; every raw conv output stored bf16 (except conv3 of the blocks without a downsample
   branch, whose BatchNorm is applied to the fp32 accumulators inside the GEMM: csrc/bnlin.hip); relu(bn(raw)) rounded to bf16 when
   it is formed in the consumer's operand load; block outputs y and the pooled stem output stored bf16; in the
-  backward pass the gradients of those same tensors are stored bf16.  BatchNorm statistics come from the fp32
+  backward pass the gradients of those same tensors are stored bf16 (except the downsample output's where its BatchNorm backward runs
+  through the moments of the block input: ds_through_moments).  BatchNorm statistics come from the fp32
   accumulators (the un-rounded conv result) and are applied to the rounded tensor; weight gradients stay fp32.
 """
 import torch
@@ -43,8 +44,21 @@ class _QW(torch.autograd.Function):
         return g
 
 
+class _QF(torch.autograd.Function):
+    """bf16 round-trip in the forward only (a stored tensor whose gradient the HIP plan never forms as a tensor of its own)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 Q = _Q.apply
 QW = _QW.apply
+QF = _QF.apply
 
 
 def _bn_train(u, uq, bn, eps=1e-5):
@@ -64,6 +78,13 @@ def stores_raw3(blk):
     import os
     w = blk.conv3.in_channels
     return not (w % 32 == 0 and w <= int(os.environ.get("DALI_BNLIN_MAXW", "512")))
+
+
+def ds_through_moments(blk, first_of_net):
+    """Does the HIP plan run the downsample BatchNorm's backward through the moments of the block input (no d_rawd tensor, resnet_plan.hip
+    `lin_ds`)?  The net's first block, when its branch is a stride-1 convolution of at most 128 channels and bn3 goes through moments too."""
+    d = blk.downsample
+    return (first_of_net and d is not None and d[0].stride == (1, 1) and d[0].in_channels % 32 == 0 and d[0].in_channels <= 128 and not stores_raw3(blk))
 
 
 def _conv(x, conv):
@@ -86,6 +107,7 @@ def forward_matched(model, x, training=True):
     u = _conv(x, model.conv1)
     z = _bn(u, Q(u), model.bn1)                   # no ReLU after the stem BN (Encoders.py:334)
     x = Q(F.max_pool2d(z, 3, 2, 1))
+    first = True
     for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
         for blk in layer:
             u1 = _conv(x, blk.conv1)
@@ -97,9 +119,10 @@ def forward_matched(model, x, training=True):
             out = _bn(u3, Q(u3) if stores_raw3(blk) else u3, blk.bn3)
             if blk.downsample is not None:
                 ud = _conv(x, blk.downsample[0])
-                idn = _bn(ud, Q(ud), blk.downsample[1])
+                idn = _bn(ud, (QF if ds_through_moments(blk, first) else Q)(ud), blk.downsample[1])
             else:
                 idn = x
+            first = False
             x = Q(F.relu(out + idn))
     f = x.mean((2, 3)) + F.adaptive_max_pool2d(x, 1).flatten(1)     # Encoders.py:341-345
     return _bn(f, f, model.last_bn)               # BatchNorm1d neck in fp32
