@@ -154,8 +154,10 @@ def check(status, what=""):
         raise DaliError("%s failed with status %d: %s" % (what or "libdaliid_hip call", status, last_error()))
 
 
-def ctx(device=None):
-    """One dali_ctx per device ordinal, created on first use."""
+def ctx(device=None, lane=0):
+    """One dali_ctx per (device ordinal, lane), created on first use.  A context owns ONE grow-only workspace block that its calls use from
+    offset 0, i.e. it serves one stream at a time (include/daliid.h, dali_ctx_create): work enqueued on a second stream that may run beside
+    the main stream's (transforms.finish on its side stream) goes through its own context, ``lane="side"``."""
     if not torch.cuda.is_available():
         raise DaliError("daliid_amd needs a gfx950 GPU (torch.cuda.is_available() is False); there is no CPU path")
     if device is None:
@@ -168,14 +170,15 @@ def ctx(device=None):
         # lives elsewhere must be handled under `with torch.cuda.device(...)`
         raise DaliError("tensors live on cuda:%d but the current device is cuda:%d; wrap the call in torch.cuda.device(%d)"
                         % (device, torch.cuda.current_device(), device))
-    c = _ctxs.get(device)
+    key = device if lane == 0 else (device, lane)
+    c = _ctxs.get(key)
     if c is None:
         with _lock:
-            c = _ctxs.get(device)
+            c = _ctxs.get(key)
             if c is None:
                 h = c_void_p()
                 check(lib().dali_ctx_create(device, ctypes.byref(h)), "dali_ctx_create")
-                c = _ctxs[device] = h
+                c = _ctxs[key] = h
     return c
 
 

@@ -2694,6 +2694,9 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         if (!(k64 && (cfg == CONV_256x256 || cfg == CONV_128x256)) && !narrow) { cfg = CONV_128; k64 = 0; }
     }
     if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !((K >= 1024 && (cfg == CONV_256x256 || cfg == CONV_128x256)) || (K >= 768 && cfg == CONV_256x256))) k64 = 0;
+    // a second operand tensor is only read by the SRC2 instantiations: the two k-tile-64 kernels above (k64 still set) or, for every other
+    // choice -- including a k64 that the K gate has just cleared -- the 128 x 128 / 64 x 256 LDS-DMA kernel
+    if (a.X2 && !narrow && !(k64 && (cfg == CONV_256x256 || cfg == CONV_128x256))) { cfg = CONV_128; k64 = 0; }
     // fused output stage (IGemmArgs::out_scale ... out_mask): its own instantiations of three kernels, so that the convolutions' hot
     // instantiations compile none of it (code that is never executed still cost their register allocation 0.4-0.8 ms per step)
     const bool fused = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;
@@ -2830,8 +2833,8 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
         const int grid = xcd_tile_grid(tiles_m, tiles_n);
         if (in_bn) hipLaunchKernelGGL((igemm_conv_kernel<128, 128, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
-        else if (dma_ok && conv_cfg_override() == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else if (dma_ok && a.X2) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, 0, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
+        else if (dma_ok && conv_cfg_override() == 0) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 2>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);
         else if (dma_ok && lin) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3, true>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else if (dma_ok) hipLaunchKernelGGL((igemm_conv_dma_kernel<128, 128, 3>), dim3(grid), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_kernel<128, 128, false>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, args, tiles_m, tiles_n);

@@ -234,6 +234,11 @@ class LossHeads:
         self.proxies = proxies.contiguous()
         self.clabels, self.plabels = _codes(centers_labels, dev), _codes(proxies_labels, dev)
         self.tau, self.lam, self.pg = float(tau), float(lambda_proxy), process_group
+        # the kernel keeps one identity's positives in registers (dali_proxy_kmax()); its device-side status word is not read in the hot
+        # loop (no host sync there), so the limit is enforced here, once per epoch, on the host copy of the labels
+        plab = np.asarray(proxies_labels)
+        if plab.size and int(np.unique(plab, return_counts=True)[1].max()) > _kmax():
+            raise _lib.DaliError("LossHeads: an identity has more than %d proxies (documented limit of dali_proxy_loss_fwd)" % _kmax())
 
     def __call__(self, fn, labels, w):
         """fn [nb,D] normalised embeddings, labels int32 codes, w [nb] -> (stats[4] = c_num, c_den, p_num, p_den (global),

@@ -9,7 +9,18 @@ DataParallel semantics, Encoders.py:88-89) and exchanges exactly
   2. one all-reduce(SUM, not mean) of the flat gradient buffer per backward stage (4 buckets: layer4+neck 15.0 M,
      layer3 7.1 M, layer2 1.2 M, layer1+stem 0.2 M floats), each launched on a side stream as soon as its stage is
      enqueued so it overlaps the remaining backward.  xGMI is a point-to-point mesh: few large buckets beat many small.
-Adam and the EMA then run redundantly on identical data on every rank (no weight broadcast, ever).
+Adam and the EMA then run redundantly on identical data on every rank: WEIGHTS are never broadcast.
+
+BatchNorm running statistics are the one piece of state that is rank-local during the PK loop (each rank's forward folds in
+its own shard's batch statistics).  Under ``nn.DataParallel`` only replica 0's buffers survive a forward (replica 0 shares
+storage with the wrapped module, Encoders.py:39-40), so after the loop -- before anything runs in eval mode -- every rank
+takes rank 0's ``flat_buffers`` / ``flat_nbt`` of the online AND the momentum net (``sync_buffers_from_rank0``; rank 0's
+momentum buffers are the EMA of rank 0's online buffers, which is what the reference's EMA over state_dict sees).  Train mode
+never reads the running statistics, so one broadcast per epoch gives the same bits as one per step.
+
+Epoch inference (``extractFeatures`` over the whole train set, train_encodersKIT.py:104-110, which DataParallel splits over the
+GPUs batch by batch, getFeatures.py:56-67) is sharded: every rank extracts one contiguous slice and ONE all-gather hands every rank
+the full ``[N, D]`` fp32 matrix (``extract_features_sharded``), so that all ranks derive identical centers / proxies.
 
 The gradient buckets go either through ``torch.distributed`` (default) or, with ``DALIID_COMM=abi``, through the library's own RCCL
 communicator (``dali_allreduce_bucket``, include/daliid.h): torch.distributed then only carries the 128-byte unique id to the ranks.
@@ -132,3 +143,59 @@ class GradReducer:
         self.works = []
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
+
+
+def slice_bounds(n, world):
+    """Contiguous, near-equal slices of ``n`` rows over ``world`` ranks: [0, ..., n] with world + 1 entries."""
+    per, extra = divmod(n, world)
+    b = [0]
+    for r in range(world):
+        b.append(b[-1] + per + (1 if r < extra else 0))
+    return b
+
+
+def sync_buffers_from_rank0(nets, group=None):
+    """Every rank takes rank 0's BatchNorm running statistics and ``num_batches_tracked`` counters (DataParallel keeps replica 0's,
+    Encoders.py:39-40).  ``nets``: modules on flat storage (``flat_buffers`` fp32, ``flat_nbt`` int64)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    for net in nets:
+        net = getattr(net, "module", net)
+        dist.broadcast(net.flat_buffers, src=src, group=group)
+        dist.broadcast(net.flat_nbt, src=src, group=group)
+
+
+def buffers_in_sync(nets, group=None):
+    """True on every rank iff all ranks hold bit-identical running statistics (one all-reduce of 2 x len(nets) checksum words:
+    MIN and MAX of an order-independent integer checksum agree only for identical bits)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    sums = []
+    for net in nets:
+        net = getattr(net, "module", net)
+        bits = net.flat_buffers.view(torch.int32).to(torch.int64)
+        idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+        sums.append((bits * idx).sum() + net.flat_nbt.sum() * 1000003)           # int64 wrap-around is fine: equal bits, equal sums
+    lo = torch.stack(sums)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
+
+
+def all_gather_rows(local, bounds, group=None):
+    """local [bounds[r+1] - bounds[r], D] on rank r -> the full [bounds[-1], D] matrix on every rank (one all-gather of equal-sized,
+    zero-padded blocks; xGMI is point to point, so one large collective beats one per inference batch)."""
+    world = dist.get_world_size(group)
+    n = bounds[-1]
+    d = local.shape[1]
+    per = max(bounds[r + 1] - bounds[r] for r in range(world))
+    send = torch.zeros(per, d, device=local.device, dtype=local.dtype)
+    send[:local.shape[0]] = local
+    recv = torch.empty(world * per, d, device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(recv, send, group=group) if local.is_cuda and dist.get_backend(group) == "nccl" else \
+        dist.all_gather(list(recv.view(world, per, d).unbind(0)), send, group=group)
+    if all(bounds[r + 1] - bounds[r] == per for r in range(world)):
+        return recv[:n]
+    return torch.cat([recv[r * per:r * per + bounds[r + 1] - bounds[r]] for r in range(world)], 0)

@@ -51,7 +51,7 @@ def selectProxiesByTriagulation(X, num_proxies=5):
     return rows, max_dist.item()
 
 
-def build_centers_and_proxies(fvs, labels, num_proxies=5):
+def build_centers_and_proxies(fvs, labels, num_proxies=5, process_group=None):
     """train_encodersKIT.py:113-156 on device-resident features: per class, proxies by farthest-point sampling and
     the center = mean of the un-normalised embeddings; both L2-normalised (no epsilon).  The per-class Python loop of
     the reference becomes one kernel launch (one block per identity); the host only sorts the labels and draws the
@@ -63,6 +63,8 @@ def build_centers_and_proxies(fvs, labels, num_proxies=5):
     order = np.argsort(labels, kind="stable").astype(np.int32)
     bounds = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
     first = np.array([np.random.choice(int(n)) for n in counts], dtype=np.int32)
+    if process_group is not None:          # one process draws in the reference; the ranks' numpy streams have diverged in the PK loop
+        first = parallel.broadcast_from_rank0(first, process_group)
     dev = fvs.device
     centers, proxies, rows, max_dist = ops_eval.class_targets(
         fvs.contiguous().float(), torch.from_numpy(order).to(dev), torch.from_numpy(bounds).to(dev), torch.from_numpy(first).to(dev),
@@ -86,6 +88,9 @@ class samplePKBatches:
 
     def __init__(self, dataset, images, labels, img_height, img_width, turbulance_dir_path, kind_of_transform, K=4, turb_strength=0):
         self.images_names = images[:, 0]
+        # column 3 = kind of record (datasetUtils.py:15); only 'person' rows are ever put in a batch (train_encodersKIT.py:299, :348).
+        # Record arrays without that column (in-memory synthetic sets) are all persons.
+        self.reid_instances = images[:, 3] if images.shape[1] > 3 else None
         self.labels = np.asarray(labels)
         self.labels_set = np.unique(labels)
         self.K = K
@@ -96,10 +101,21 @@ class samplePKBatches:
     def __len__(self):
         return len(self.labels_set)
 
+    def _select(self, pid):
+        """The identity's files and the up-to-K picks among them (train_encodersKIT.py:329-339): the draw runs over ALL rows of the identity,
+        then rows whose kind is not 'person' are dropped without drawing anything for them (:348: the whole body sits under that test)."""
+        rows = self.labels == pid
+        names = self.images_names[rows]
+        sel = np.random.choice(names.shape[0], size=min(names.shape[0], self.K), replace=False)
+        if self.reid_instances is not None:
+            sel = sel[self.reid_instances[rows][sel] == "person"]
+            if len(sel) == 0:              # the reference dies here too (``[].shape``, :397): say why
+                raise _lib.DaliError("samplePKBatches: identity %r has no 'person' record among its picks" % (pid,))
+        return names, sel
+
     def __getitem__(self, idx):
         pid = self.labels_set[idx]
-        names = self.images_names[self.labels == pid]
-        sel = np.random.choice(names.shape[0], size=min(names.shape[0], self.K), replace=False)
+        names, sel = self._select(pid)
         loader = get_train_loader()
         clean = loader(list(names[sel]), self.img_height, self.img_width, None)
         if self.kind_of_transform == 0:
@@ -118,8 +134,7 @@ class samplePKBatches:
         (clean, distorted, clean, distorted ...) order -- so that a whole PK batch is decoded on the pool and resized + augmented by one
         launch each (``plan_batch`` / ``finish_batch``).  -> (ImagePlan, labels tensor, distortion levels)"""
         pid = self.labels_set[idx]
-        names = self.images_names[self.labels == pid]
-        sel = np.random.choice(names.shape[0], size=min(names.shape[0], self.K), replace=False)
+        names, sel = self._select(pid)
         clean = loader.plan(list(names[sel]), self.img_height, self.img_width, None)
         if self.kind_of_transform == 0:
             plan, dist = clean, np.zeros(len(sel), dtype=np.int32)
@@ -169,12 +184,33 @@ class trainer(object):
         self.last_epoch_stats = None
 
     # ---- epoch-level: inference over the train set, centers, proxies (train_encodersKIT.py:104-156) ----
+    def extract_train_features(self, selected_images):
+        """train_encodersKIT.py:104-110.  With a process group the train set is cut into one contiguous slice per rank (nn.DataParallel
+        splits every 500-image batch over the GPUs instead, getFeatures.py:56-67; eval-mode features do not depend on the split) and one
+        all-gather gives every rank all rows, in dataset order: all ranks then build the same centers and proxies."""
+        if self.process_group is None:
+            return extractFeatures(selected_images, self.img_height, self.img_width, self.model_online, 500, gpu_index=self.gpu_indexes[0],
+                                   keep_on_device=True)
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        if not parallel.buffers_in_sync((self.model_online,), self.process_group):
+            raise _lib.DaliError("data parallel: BatchNorm running statistics differ between ranks before the epoch inference "
+                                 "(parallel.sync_buffers_from_rank0 runs at the end of trainer.train; load the same checkpoint on every rank)")
+        bounds = parallel.slice_bounds(len(selected_images), world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        local = extractFeatures(selected_images[lo:hi], self.img_height, self.img_width, self.model_online, 500, gpu_index=self.gpu_indexes[0],
+                                keep_on_device=True)
+        if local.shape[0] == 0:
+            local = local.new_zeros(0, getattr(self._net, "feat_dim", None) or self._net.in_planes)
+        self.last_inference_rows = hi - lo
+        return parallel.all_gather_rows(local.float().contiguous(), bounds, self.process_group)
+
     def build_targets(self, selected_images, selected_labels):
         self.model_online.eval()
         print("Number of samples for proxies generation: %d" % selected_images.shape[0])
-        fvs = extractFeatures(selected_images, self.img_height, self.img_width, self.model_online, 500, gpu_index=self.gpu_indexes[0],
-                              keep_on_device=True)
-        centers, centers_labels, all_proxies, proxies_labels, mean_max = build_centers_and_proxies(fvs, selected_labels, self.num_proxies)
+        fvs = self.extract_train_features(selected_images)
+        centers, centers_labels, all_proxies, proxies_labels, mean_max = build_centers_and_proxies(fvs, selected_labels, self.num_proxies,
+                                                                                                     self.process_group)
         pd = ops_eval.pairdist(all_proxies, all_proxies, metric="l2sq").clamp_(min=0).sqrt_()      # the cdist statistic, :148-153
         same = torch.from_numpy(proxies_labels[:, None] == proxies_labels[None, :]).to(pd.device)
         min_distance = torch.where(same, pd.max(), pd).min().item()
@@ -221,7 +257,7 @@ class trainer(object):
             if bs % world != 0 or bs < 3:
                 raise _lib.DaliError("data parallel: P=%d identities per batch must be >= 3 and divide over %d ranks" % (bs, world))
             event_dataset.labels_set = parallel.broadcast_from_rank0(event_dataset.labels_set, self.process_group)
-        heads = self.build_targets(selected_images, selected_labels)
+        heads = self.last_targets = self.build_targets(selected_images, selected_labels)
         self.model_online.train()
         self.model_momentum.eval()
         for inner_iter in np.arange(number_of_iterations):
@@ -262,5 +298,8 @@ class trainer(object):
             print("Mean Center Loss: %.7f, Mean Proxy Loss: %.7f" % (a[0] / nb, a[1] / nb))
             print("Mean Final Loss: %.7f" % (a[2] / nb))
             print("Mean Weights Sum: %.2f" % (a[3] / nb))
+        # nn.DataParallel keeps replica 0's BatchNorm running statistics (Encoders.py:39-40): every rank takes rank 0's, for the online net
+        # and for the momentum net (whose buffers are the EMA of rank 0's), before anything runs in eval mode
+        parallel.sync_buffers_from_rank0((self._net, self._mom), self.process_group)
         self.model_online.eval()
         self.model_momentum.eval()

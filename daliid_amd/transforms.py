@@ -75,9 +75,10 @@ def resize_u8_reference(img, out_h, out_w):
     return one_pass(tmp.transpose(1, 0, 2), out_h).transpose(1, 0, 2)       # then vertical
 
 
-def resize_bicubic_u8(images, out_h, out_w, device=None):
+def resize_bicubic_u8(images, out_h, out_w, device=None, lane=0):
     """images: sequence of uint8 [h,w,3] arrays (numpy or CPU tensors) of any sizes -> uint8 CUDA tensor [N,out_h,out_w,3]
-    = PIL ``img.resize((out_w, out_h), Image.BICUBIC)`` for each."""
+    = PIL ``img.resize((out_w, out_h), Image.BICUBIC)`` for each.  The horizontally resampled intermediate lives in the workspace of
+    the context ``_lib.ctx(device, lane)``: a caller on a stream that runs beside the main one passes its own lane."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     arrs = [np.ascontiguousarray(np.asarray(im), dtype=np.uint8) for im in images]
     n = len(arrs)
@@ -105,7 +106,7 @@ def resize_bicubic_u8(images, out_h, out_w, device=None):
     t_tab = up(np.array([tab[a.shape[:2]] for a in arrs], np.int32))
     t_bh, t_ch, t_bv, t_cv = up(bh), up(ch), up(bv), up(cv)
     max_in_h = max(a.shape[0] for a in arrs)
-    _lib.check(_lib.lib().dali_resize_bicubic_u8(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(packed), _lib.ptr(t_off), _lib.ptr(t_h), _lib.ptr(t_w),
+    _lib.check(_lib.lib().dali_resize_bicubic_u8(_lib.ctx(dev, lane), _lib.stream_ptr(), _lib.ptr(packed), _lib.ptr(t_off), _lib.ptr(t_h), _lib.ptr(t_w),
                                                   _lib.ptr(t_tab), n, max_in_h, _lib.ptr(t_bh), _lib.ptr(t_ch), ks_h, _lib.ptr(t_bv), _lib.ptr(t_cv),
                                                   ks_v, out_h, out_w, _lib.ptr(out)), "dali_resize_bicubic_u8")
     return out
@@ -260,7 +261,9 @@ def finish(ticket, device=None, side_stream=True):
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     with torch.cuda.stream(side):
-        u8 = resize_bicubic_u8(arrs, plan.height, plan.width, dev)
+        # the side stream's own context: the resize keeps its intermediate in the context's workspace, and the main stream's kernels (Adam's
+        # partial sums, the targets, the distance pre-pass) use THEIR context's workspace at the same time
+        u8 = resize_bicubic_u8(arrs, plan.height, plan.width, dev, lane="side")
         out = augment(u8, plan.params)
     main.wait_stream(side)
     out.record_stream(main)

@@ -33,14 +33,25 @@ class validateModels:
         """``validate`` with the gallery split over the ranks of ``process_group`` (one process per GPU): every rank extracts
         the query features and the features of ITS contiguous gallery slice, computes its [Nq, Ng / N] block of ``1 - q @ g.T`` and the
         ranks merge per-query hit counts (ops_eval.rank_eval_sharded: one all-gather of match keys, one all-reduce of integer bins).
-        -> (cmc, mAP, this rank's distance block); cmc / mAP are identical on every rank and equal to the single-GPU result bit for bit."""
+        -> (cmc, mAP, this rank's distance block); cmc / mAP are identical on every rank and, GIVEN the same model state on every rank,
+        equal to the single-GPU result bit for bit.  The weights are identical by construction (parallel.py); the BatchNorm running
+        statistics are rank-local during training and are made rank 0's at the end of every ``trainer.train`` epoch
+        (parallel.sync_buffers_from_rank0, the nn.DataParallel semantics of Encoders.py:39-40).  A model whose statistics still differ
+        between ranks is refused here, collectively, before any feature is extracted."""
         import torch.distributed as dist
+        from . import _lib, parallel
         world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         model.eval()
+        if not parallel.buffers_in_sync((model,), process_group):
+            raise _lib.DaliError("validate_sharded: BatchNorm running statistics differ between ranks "
+                                 "(call parallel.sync_buffers_from_rank0 or load the same checkpoint on every rank)")
         lo, hi = ops_eval.shard_bounds(len(gallery), world)[rank:rank + 2]
         queries_fvs = extractFeatures(queries, self.img_height, self.img_width, model, 500, self.gpu_index, keep_on_device=True)
-        gallery_fvs = extractFeatures(gallery[lo:hi], self.img_height, self.img_width, model, 500, self.gpu_index, keep_on_device=True)
+        if hi > lo:
+            gallery_fvs = extractFeatures(gallery[lo:hi], self.img_height, self.img_width, model, 500, self.gpu_index, keep_on_device=True)
+        else:                  # trailing ranks of a small gallery hold no rows (128-row aligned slices): an empty block, same collectives
+            gallery_fvs = queries_fvs.new_zeros(0, queries_fvs.shape[1])
         block = self.distance(queries_fvs, gallery_fvs)
         del queries_fvs, gallery_fvs
         cmc, mAP = ops_eval.rank_eval_sharded(block, queries[:, 1], gallery[lo:hi, 1], queries[:, 2], gallery[lo:hi, 2], lo, process_group,

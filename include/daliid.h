@@ -38,7 +38,10 @@ typedef struct dali_ctx dali_ctx;
 /* ---- context ---------------------------------------------------------------------------------- */
 int dali_version(void);
 const char* dali_last_error(void);
-/* One context per process / GPU.  `device` is the HIP device ordinal. */
+/* One context per process / GPU and per stream that may run beside another: `device` is the HIP device ordinal.  A context owns one
+ * grow-only workspace block that its calls use from offset 0 (Adam's partial sums, the resize's intermediate image, the distance
+ * pre-pass, the class targets), so two calls on the SAME context must not overlap in time: enqueue them on one stream, or give the
+ * second stream its own context (the Python side does: `_lib.ctx(device, lane="side")` for the input pipeline's side stream). */
 int dali_ctx_create(int device, dali_ctx** out);
 int dali_ctx_destroy(dali_ctx* ctx);
 /* Pre-size the workspace (hipMalloc happens here, not inside later calls / graph captures). */

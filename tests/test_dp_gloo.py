@@ -122,3 +122,64 @@ def test_gallery_shard_bounds_cover_the_gallery_once():
         b = ops_eval.shard_bounds(n, world)
         assert len(b) == world + 1 and b[0] == 0 and b[-1] == n
         assert all(b[i] <= b[i + 1] for i in range(world)) and all(x % 128 == 0 or x == n for x in b)
+
+
+# ---- epoch-level data parallelism: rank-0 running statistics, sharded epoch inference ----
+def _epoch_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import types
+    from daliid_amd import parallel
+    from oracle.resnet50_reid import ResNet50ReID
+    parallel.init_from_env("gloo")
+    torch.manual_seed(3)
+    model = ResNet50ReID(layers=(1, 1, 1, 1), width=8)
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randn(11, 3, 32, 16, generator=g)                    # 11 rows over 2 ranks: ragged slices (6 + 5)
+    # the ranks' running statistics diverge in the PK loop (each forwards its own shard in train mode) ...
+    model.train()
+    with torch.no_grad():
+        model(imgs[rank * 4:rank * 4 + 4])
+    bufs = [b for n, b in model.named_buffers() if not n.endswith("num_batches_tracked")]
+    nbts = [b for n, b in model.named_buffers() if n.endswith("num_batches_tracked")]
+    net = types.SimpleNamespace(flat_buffers=torch.cat([b.flatten() for b in bufs]), flat_nbt=torch.stack(nbts) + rank)
+    before = parallel.buffers_in_sync((net,))
+    mine = net.flat_buffers.clone()
+    # ... and every rank takes rank 0's before anything runs in eval mode (Encoders.py:39-40)
+    parallel.sync_buffers_from_rank0((net,))
+    after = parallel.buffers_in_sync((net,))
+    o = 0
+    for b in bufs:
+        b.copy_(net.flat_buffers[o:o + b.numel()].view_as(b)); o += b.numel()
+    # sharded epoch inference: every rank forwards its contiguous slice, one all-gather hands everyone all rows in dataset order
+    model.eval()
+    bounds = parallel.slice_bounds(imgs.shape[0], world)
+    with torch.no_grad():
+        local = model(imgs[bounds[rank]:bounds[rank + 1]])
+        full = model(imgs)
+    gathered = parallel.all_gather_rows(local, bounds)
+    empty = parallel.all_gather_rows(local[:0] if rank == 1 else local[:3], [0, 3, 3])          # a rank without rows still takes part
+    torch.save({"before": before, "after": after, "mine": mine, "buf": net.flat_buffers, "nbt": net.flat_nbt, "gathered": gathered,
+                "full": full, "empty": empty, "local3": local[:3]}, os.path.join(out_dir, "epoch_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_buffers_and_sharded_inference(tmp_path):
+    world = 2
+    mp.spawn(_epoch_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "epoch_rank%d.pt" % r), weights_only=False) for r in range(world)]
+    assert not outs[0]["before"] and not outs[1]["before"] and outs[0]["after"] and outs[1]["after"]
+    assert not torch.equal(outs[0]["mine"], outs[1]["mine"])                       # they really had diverged
+    for o in outs:                                                                 # rank 0's statistics and counters everywhere
+        assert torch.equal(o["buf"], outs[0]["mine"]) and torch.equal(o["nbt"], outs[0]["nbt"])
+    assert torch.equal(outs[0]["gathered"], outs[1]["gathered"]) and outs[0]["gathered"].shape[0] == 11
+    np.testing.assert_allclose(outs[0]["gathered"].numpy(), outs[0]["full"].numpy(), rtol=1e-4, atol=1e-5)   # eval mode: split-independent
+    assert torch.equal(outs[0]["empty"], outs[0]["local3"]) and torch.equal(outs[1]["empty"], outs[0]["local3"])
+
+
+def test_slice_bounds():
+    from daliid_amd import parallel
+    assert parallel.slice_bounds(12936, 8) == [0, 1617, 3234, 4851, 6468, 8085, 9702, 11319, 12936]
+    assert parallel.slice_bounds(11, 2) == [0, 6, 11] and parallel.slice_bounds(3, 4) == [0, 1, 2, 3, 3]

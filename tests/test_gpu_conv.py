@@ -162,7 +162,10 @@ def test_splitk_reduce_alone(nn, elems, splits, accumulate):
 # (pixels, c1, c2, cout): the kernels with a second operand tensor (IGemmArgs::X2, the SRC2 instantiations) -- 64 x 256 and 128 x 128 LDS-DMA,
 # wave-specialised 128 x 256 k-tile 64 (K >= 1024, cout 128..256, P >= 16384), 256 x 256 k-tile 64 (cout >= 512); ragged pixel counts included
 @pytest.mark.parametrize("P,c1,c2,cout", [(777, 256, 64, 64), (1000, 512, 128, 128), (300, 64, 32, 24), (16640, 1024, 256, 256), (16500, 2048, 512, 512),
-                                           (16384, 1024, 64, 128)])
+                                           (16384, 1024, 64, 128),
+                                           # 512 <= K < 1024 with a wide tile picked first: the K gate clears k-tile 64, the launch must still
+                                           # land on a two-tensor kernel (round-4 advisor finding: it read x1 as [P][c1 + c2])
+                                           (16384, 448, 64, 256), (20000, 512, 256, 512)])
 def test_conv1x1_two_operand_tensors_exact_integers(nn, P, c1, c2, cout):
     """y = [x1 | x2] @ w^T + bias in ONE launch (dali_conv1x1_cat; the merged conv3 data gradient of the Gram-scheme blocks): small integers, so the
     result must equal the fp32 oracle rounded once to bf16 bit for bit."""

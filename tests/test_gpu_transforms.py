@@ -213,3 +213,44 @@ def test_extract_features_batched_path_equals_per_batch_loader_calls(T, tmp_path
     finally:
         getFeatures.set_image_loader(None)
     assert batched.shape == (15, 1024) and torch.equal(batched, sequential)
+
+
+def test_side_stream_finish_beside_workspace_users_of_the_main_stream(T):
+    """finish(side_stream=True) runs the resize on a side stream that does NOT wait for the main stream.  The resize keeps its horizontally
+    resampled intermediate in a context workspace; dali_adam_step (its partial sums of sum theta^2, every step) and dali_class_targets use
+    the workspace of the main stream's context from offset 0.  The side stream therefore has its own context (``_lib.ctx(dev, "side")``):
+    with both running at the same time, the images equal the sequential path bit for bit and the Adam statistic equals its solo value."""
+    from daliid_amd import _lib
+    dev = torch.device("cuda", 0)
+    assert _lib.ctx(dev, "side").value != _lib.ctx(dev).value
+    rng = np.random.default_rng(7)
+    imgs = _images(rng, [(160, 80)] * 48)
+    plan = T.ImagePlan(["mem://%d" % i for i in range(len(imgs))], T.eval_params(len(imgs)), 256, 128)
+    want = T.augment(T.resize_bicubic_u8(imgs, 256, 128, dev), plan.params)
+    n = 24 * 1024 * 1024                                                     # a parameter buffer of ViT size: Adam's launch takes ~0.5 ms
+    g = torch.Generator(device=dev).manual_seed(3)
+    p0 = torch.randn(n, device=dev, generator=g) * 0.1
+    grad = torch.randn(n, device=dev, generator=g) * 0.01
+    L = _lib.lib()
+
+    def adam(p, m, v, sq):
+        _lib.check(L.dali_adam_step(_lib.ctx(dev), _lib.stream_ptr(), _lib.ptr(p), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), n, 3.5e-4, 0.9, 0.999,
+                                    1e-8, 5e-4, 1, 1.0, _lib.ptr(sq)), "dali_adam_step")
+    p, m, v, sq_solo = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(1, device=dev)
+    adam(p, m, v, sq_solo)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        sqs = [torch.zeros(1, device=dev) for _ in range(6)]
+        ticket = T.submit(plan, decode=lambda f: imgs[int(f.split("/")[-1])])
+        torch.cuda.synchronize()
+        for i in range(3):
+            pi = p.clone() if i else p
+            adam(pi, m.clone(), v.clone(), sqs[i])
+        got = T.finish(ticket, dev, side_stream=True)                       # enqueued while the Adam launches above are still running
+        for i in range(3, 6):
+            adam(p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), sqs[i])
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), rep
+        for s in sqs:
+            assert torch.equal(s, sq_solo), (rep, float(s), float(sq_solo))

@@ -6,6 +6,7 @@ would feed clean pixels under a distortion label."""
 import os
 
 import numpy as np
+import torch
 import pytest
 from PIL import Image
 
@@ -84,3 +85,51 @@ def test_pk_sampler_pairs_clean_with_distorted_file(files, monkeypatch):
         assert float(labels[0]) == 2.0
     finally:
         train_encodersKIT.set_train_loader(None)
+
+
+def test_pk_sampler_keeps_person_records_only():
+    """train_encodersKIT.py:299,339,348: the K picks run over all rows of the identity, then rows whose kind (column 3) is not 'person' are
+    dropped without a draw; the plan path (batched loader protocol) makes the same selection."""
+    seen = []
+
+    def loader(paths, h, w, turb=None):
+        seen.append(list(paths))
+        return torch.zeros(len(paths), 3, h, w)
+    loader.plan = lambda paths, h, w, turb=None: type("P", (), {"files": list(paths), "concat": None})()
+    train_encodersKIT.set_train_loader(loader)
+    try:
+        recs = np.array([["a%d" % i, "5", "0", "person" if i % 2 == 0 else "vehicle"] for i in range(6)])
+        ds = train_encodersKIT.samplePKBatches("Market", recs, np.full(6, 5), 8, 4, None, 0, K=6)
+        np.random.seed(1)
+        imgs, labels, dist = ds[0]
+        assert sorted(seen[-1]) == ["a0", "a2", "a4"] and imgs.shape[0] == 3 and labels.shape[0] == 3 and len(dist) == 3
+        np.random.seed(1)
+        plan, plabels, pdist = ds.plan(0, loader)
+        assert plan.files == seen[-1] and plabels.shape[0] == 3                    # same picks, same order
+        # an identity whose picks hold no person record is an error that says so (the reference dies on ``[].shape``, :397)
+        recs2 = np.array([["b%d" % i, "7", "0", "vehicle"] for i in range(3)])
+        ds2 = train_encodersKIT.samplePKBatches("Market", recs2, np.full(3, 7), 8, 4, None, 0, K=2)
+        import pytest
+        from daliid_amd._lib import DaliError
+        with pytest.raises(DaliError):
+            ds2[0]
+        # record arrays without a kind column (in-memory synthetic sets) are all persons
+        ds3 = train_encodersKIT.samplePKBatches("Synthetic", recs[:, :3], np.full(6, 5), 8, 4, None, 0, K=6)
+        assert ds3[0][0].shape[0] == 6
+    finally:
+        train_encodersKIT.set_train_loader(None)
+
+
+def test_loss_heads_refuse_more_proxies_per_identity_than_the_kernel_holds():
+    """LossHeads never reads the kernel's status word in the hot loop (no host sync there): the documented limit dali_proxy_kmax() is
+    checked on the host when the epoch's targets are built."""
+    import pytest
+    from daliid_amd import losses
+    from daliid_amd._lib import DaliError
+    k = losses._kmax()
+    c = torch.nn.functional.normalize(torch.randn(2, 16))
+    ok = torch.nn.functional.normalize(torch.randn(2 * k, 16))
+    losses.LossHeads(c, np.arange(2), ok, np.repeat(np.arange(2), k), 0.05, 0.4)
+    bad = torch.nn.functional.normalize(torch.randn(k + 2, 16))
+    with pytest.raises(DaliError):
+        losses.LossHeads(c, np.arange(2), bad, np.array([0] * (k + 1) + [1]), 0.05, 0.4)
