@@ -372,7 +372,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     // (the sub-problems went through the general path before: 8-byte stores per lane, per-element residual loads; layer2's downsample
     // data gradient 169 us against 71 us forward), so that the hot convolution instantiations stay as they are.
     constexpr bool SUB = LIN == 4;
-    const bool plain = LIN != 3 && !a.O2 && a.act == 0 && !a.dact_pre && !a.row_scale && (SUB || !a.g.sub) && (a.Cm & 7) == 0;   // bias (linear layers) is folded in below
+    const bool plain = LIN != 3 && LIN != 5 && !a.O2 && a.act == 0 && !a.dact_pre && !a.row_scale && (SUB || !a.g.sub) && (a.Cm & 7) == 0;   // bias (linear layers) is folded in below
     // the linear layers' GELU / pre-activation copy (O2) / GELU' factor take a second staged block further down, kept apart so that the
     // convolutions' path stays as lean as it was (folding them into one block cost the ResNet step 0.8 ms)
     // (only in the LIN instantiations of the kernels: compiled into every kernel it changed the convolutions' register allocation and
@@ -380,7 +380,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
     const bool plain_ext = LIN == 1 && !plain && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre);
     const bool interior = (tm + 1) * TM <= a.Cm && (tn + 1) * TN <= a.P;
     if constexpr (!EVEN) {
-        if (interior && LIN != 3 && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre) && (unsigned long long)a.P * a.Cm * 2ull < 0xffffffffull) { conv_epilogue_cols<TM, TN, FM_, FN_, WNW, NT>(a, acc, tm, tn, smem, wm, wn); return; }
+        if (interior && LIN != 3 && LIN != 5 && !a.g.sub && (a.Cm & 7) == 0 && !(a.Res && a.dact_pre) && (unsigned long long)a.P * a.Cm * 2ull < 0xffffffffull) { conv_epilogue_cols<TM, TN, FM_, FN_, WNW, NT>(a, acc, tm, tn, smem, wm, wn); return; }
     }
     if constexpr (EVEN) if (plain && interior) {
         constexpr int ROWB = TM * 2 + 32;                       // LDS row pitch in bytes (+32: spreads the 8-byte accesses over banks)
@@ -547,7 +547,14 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         return;
     }
 
-    if constexpr (LIN == 3 && EVEN) if (interior && !a.g.sub && (a.Cm & 7) == 0) {     // fused output stage (see IGemmArgs): staged like the lean path
+    // LIN == 5: the fused output stage WITHOUT residual, masks and mask bits (scale / shift / bias / ReLU only): the inference forward's
+    // conv + BatchNorm + ReLU launches on the 3x3 and narrow kernels, whose register budgets the full stage's residual prefetch overflowed
+    if constexpr ((LIN == 3 || LIN == 5) && EVEN) if (interior && !a.g.sub && (a.Cm & 7) == 0) {     // fused output stage (see IGemmArgs): staged like the lean path
+        constexpr bool FULL = LIN == 3;
+        const uint16_t* const Res = FULL ? a.Res : nullptr;
+        const uint8_t* const out_mask = FULL ? a.out_mask : nullptr;
+        const uint8_t* const res_mask = FULL ? a.res_mask : nullptr;
+        uint8_t* const bits_out = FULL ? a.bits_out : nullptr;
         constexpr int ROWB = TM * 2 + 32;
         constexpr int HFN = FN_ / 2, WROWS = HFN * 16, ROWS = TN / 2, CPR = TM / 8, ITERS = ROWS * CPR / NT;
         static_assert(ROWS * CPR % NT == 0 && NT % CPR == 0, "staged store: threads must tile the half evenly");
@@ -574,9 +581,9 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
         }
         // the residual tile of BOTH halves is requested up front: the second half's loads fly while the first half is formed and stored
         // (requested per half they exposed one HBM round trip per half: these kernels are short-K, their epilogue is most of their time)
-        constexpr bool PRE = NT == 256;          // (the 512-thread 128 x 256 kernel would leave its 128-register budget = two workgroups per CU)
-        uint4 rpre[2][ITERS];
-        if (PRE && a.Res) {
+        constexpr bool PRE = FULL && NT == 256;          // (the 512-thread 128 x 256 kernel would leave its 128-register budget = two workgroups per CU)
+        uint4 rpre[2][PRE ? ITERS : 1];
+        if (PRE && Res) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const size_t gbase = ((size_t)(tn * TN + h * WROWS) * a.Cm + tm * TM + ch * 8) * 2;
@@ -584,7 +591,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 for (int it = 0; it < ITERS; ++it) {
                     const int lp = lp0 + it * (NT / CPR);
                     const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
-                    rpre[h][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + gbase + (size_t)q * a.Cm * 2);
+                    rpre[h][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Res) + gbase + (size_t)q * a.Cm * 2);
                 }
             }
         }
@@ -594,21 +601,21 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
             // the mask bytes of this half, requested together and early: "if (mask) m = mask[..]" inside the unrolled loops below compiled to a
             // branch and a wait around every byte load (up to 16 dependent round trips per tile; MI355X guide, the per-element select trap)
             unsigned om[ITERS], rm[ITERS];
-            if (a.out_mask) {
+            if (out_mask) {
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
                     const int lp = lp0 + it * (NT / CPR);
-                    om[it] = a.out_mask[(gbase + (size_t)((lp / WROWS) * (FN_ * 16) + (lp % WROWS)) * a.Cm * 2) >> 4];
+                    om[it] = out_mask[(gbase + (size_t)((lp / WROWS) * (FN_ * 16) + (lp % WROWS)) * a.Cm * 2) >> 4];
                 }
             }
-            if (a.Res && a.res_mask) {
+            if (Res && res_mask) {
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
                     const int lp = lp0 + it * (NT / CPR);
-                    rm[it] = a.res_mask[(gbase + (size_t)((lp / WROWS) * (FN_ * 16) + (lp % WROWS)) * a.Cm * 2) >> 4];
+                    rm[it] = res_mask[(gbase + (size_t)((lp / WROWS) * (FN_ * 16) + (lp % WROWS)) * a.Cm * 2) >> 4];
                 }
             }
-            if (a.Res) {
+            if (Res) {
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
                     const int lp = lp0 + it * (NT / CPR);
@@ -616,8 +623,8 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     const size_t rb = gbase + (size_t)q * a.Cm * 2;
                     uint4 rv;
                     if constexpr (PRE) rv = rpre[h][it];
-                    else rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Res) + rb);
-                    if (a.res_mask) {
+                    else rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Res) + rb);
+                    if (res_mask) {
                         const unsigned m = rm[it];
                         rv.x = gate_bf16x2(rv.x, m); rv.y = gate_bf16x2(rv.y, m >> 2); rv.z = gate_bf16x2(rv.z, m >> 4); rv.w = gate_bf16x2(rv.w, m >> 6);
                     }
@@ -634,7 +641,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     float v0 = acc[i][j][0] * sc4[i].x + sh4[i].x, v1 = acc[i][j][1] * sc4[i].y + sh4[i].y;
                     float v2 = acc[i][j][2] * sc4[i].z + sh4[i].z, v3 = acc[i][j][3] * sc4[i].w + sh4[i].w;
                     uint2* slot = reinterpret_cast<uint2*>(my_stage + jj * 16 * ROWB + i * 32);
-                    if (a.Res) {
+                    if (Res) {
                         const uint2 rv = *slot;
                         if (a.res_scale) {                      // (loaded per use: L1-resident; held across the tile it cost 16 registers and spills)
                             const float4 rs = *reinterpret_cast<const float4*>(a.res_scale + tm * TM + mb + i * 16);
@@ -656,12 +663,12 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                 const int q = (lp / WROWS) * (FN_ * 16) + (lp % WROWS);
                 const size_t ob = gbase + (size_t)q * a.Cm * 2;
                 uint4 v = *reinterpret_cast<const uint4*>(stage + lp * ROWB + ch * 16);
-                if (a.out_mask) {
+                if (out_mask) {
                     const unsigned m = om[it];
                     v.x = gate_bf16x2(v.x, m); v.y = gate_bf16x2(v.y, m >> 2); v.z = gate_bf16x2(v.z, m >> 4); v.w = gate_bf16x2(v.w, m >> 6);
                 }
                 *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.O) + ob) = v;
-                if (a.bits_out) a.bits_out[ob >> 4] = (uint8_t)(pos_bits_bf16x2(v.x) | (pos_bits_bf16x2(v.y) << 2) | (pos_bits_bf16x2(v.z) << 4) | (pos_bits_bf16x2(v.w) << 6));
+                if (bits_out) bits_out[ob >> 4] = (uint8_t)(pos_bits_bf16x2(v.x) | (pos_bits_bf16x2(v.y) << 2) | (pos_bits_bf16x2(v.z) << 4) | (pos_bits_bf16x2(v.w) << 6));
             }
             if (h == 0) lds_barrier();
         }
@@ -680,7 +687,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
             if (p < a.P && c < a.Cm) {      // Cm is a multiple of 4: the 4 channels are all valid
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const size_t o = opix * a.Cm + c;
-                if constexpr (LIN == 3) {
+                if constexpr (LIN == 3 || LIN == 5) {
                     if (a.out_scale) { const float4 sv = *reinterpret_cast<const float4*>(a.out_scale + c); v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w; }
                     if (a.out_shift) { const float4 sv = *reinterpret_cast<const float4*>(a.out_shift + c); v[0] += sv.x; v[1] += sv.y; v[2] += sv.z; v[3] += sv.w; }
                 }
@@ -708,7 +715,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     for (int t = 0; t < 4; ++t) v[t] *= rs;
                 }
                 }
-                if (a.Res) {
+                if (LIN != 5 && a.Res) {
                     uint2 rv = *reinterpret_cast<const uint2*>(a.Res + o);
                     if (a.res_mask) {                           // o is a multiple of 4: this lane's nibble of the mask byte
                         const unsigned m = a.res_mask[o >> 3] >> (o & 4);
@@ -722,6 +729,7 @@ __device__ __forceinline__ void conv_epilogue_g(const IGemmArgs& a, f32x4_t (&ac
                     v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
                 }
                 uint2 ov = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                if constexpr (LIN == 5) { if (a.out_relu) ov = make_uint2(pack_bf16x2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), pack_bf16x2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f))); }
                 if constexpr (LIN == 3) {
                     if (a.out_relu) ov = make_uint2(pack_bf16x2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), pack_bf16x2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)));
                     if (a.out_mask) {
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(256, (TM >= 128 ? (EPI == 3 ? 3 : 4) : 2)) void ige
     __syncthreads();
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
 
-    conv_epilogue<Cfg, (TM == 128 && TN == 128 && NSTAGE == 3) ? EPI : 2>(a, acc, tm, tn, smem);
+    conv_epilogue<Cfg, ((TM == 128 && TN == 128 && NSTAGE == 3) || EPI == 3 || EPI == 5) ? EPI : 2>(a, acc, tm, tn, smem);
     if (a.stamps) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();   // all stores issued (not yet acknowledged)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have been acknowledged
@@ -1215,7 +1223,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_conv_k64_kernel(IGemmArgs 
 // costs the issuing wave 60-185 cycles in which it cannot issue MFMAs, and the feed time added to the MFMA time instead of
 // hiding under it (ablations in scripts/ablate_conv.py, same finding and same cure as pairdist_dma_kernel in eval.hip).
 // The producers leave after the last k-step; the epilogue's barriers then count the consumers only.
-template <int WM, int WN, int NP, int NSTAGE, int FM = 4, int FN = 4, bool LIN = false, bool SRC2 = false>
+template <int WM, int WN, int NP, int NSTAGE, int FM = 4, int FN = 4, int EPI = 0, bool SRC2 = false>      // EPI: as igemm_conv_dma_kernel
 __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TM = 16 * FM * WM, TN = 16 * FN * WN, NC = WM * WN, NT = NC * 64;       // consumer sub-tile 16 FM x 16 FN
     constexpr int A_BLK = TM / 8 / NP, B_BLK = TN / 8 / NP, NDMA = A_BLK + B_BLK;
@@ -1352,7 +1360,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
         st_cur = (st_cur == NSTAGE - 1) ? 0 : st_cur + 1;
     }
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 2] = __builtin_amdgcn_s_memrealtime();
-    conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 2 && WN == 4 && NP == 8 && NSTAGE == 3) ? (LIN ? 1 : 0) : 2>(a, acc, tm, tn, smem, wm, wn);
+    conv_epilogue_g<TM, TN, FM, FN, WN, NT, (WM == 2 && WN == 4 && NP == 8 && NSTAGE == 3) ? EPI : 2>(a, acc, tm, tn, smem, wm, wn);
     if (a.stamps) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1374,7 +1382,7 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) void igemm_conv_k64s_kernel(IG
 // mode 0: input pixel (h - 1 + kr, w - 1 + ks); mode 1 (data gradient, stride 1): (h + 1 - kr, w + 1 - ks): the same patch, taps mirrored.
 // ------------------------------------------------------------------------------------------------
 constexpr int HALO64_PX = 344;                           // >= (256 / W + 2) * (W + 2) for W = 16 (324), 32 (340); 43 DMA pieces of 8 pixels
-template <int NSTAGE>
+template <int NSTAGE, int EPI = 0>                    // EPI = 3: the fused output stage (IGemmArgs::out_scale ...), its own instantiation
 __global__ __launch_bounds__(512, 4) void igemm_conv_halo64_kernel(IGemmArgs a, int tiles_n) {
     constexpr int TM = 64, TN = 256, NC = 4, NP = 4, NT = NC * 64, FM = 4, FN = 4;
     constexpr int A_ELEMS = TM * 64, RING = NSTAGE * A_ELEMS, NPIECE = HALO64_PX / 8, PPW = (NPIECE + NP - 1) / NP;   // 43 pieces, 11 per producer
@@ -1474,7 +1482,7 @@ __global__ __launch_bounds__(512, 4) void igemm_conv_halo64_kernel(IGemmArgs a, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of this weight stage are complete before it can be refilled
         __builtin_amdgcn_s_barrier();
     }
-    conv_epilogue_g<TM, TN, FM, FN, 4, NT, 2>(a, acc, 0, tn, smem, 0, wn);
+    conv_epilogue_g<TM, TN, FM, FN, 4, NT, (EPI == 3 || EPI == 5) ? EPI : 2>(a, acc, 0, tn, smem, 0, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2710,7 +2718,28 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 256) * 64 * 2 * 2));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_wg_kernel<2, 4, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 256) * 32 * 2 * 3));
         });
-        if (k64 && cfg == CONV_256x256) {
+        // the inference forward (dali_resnet_forward, training = 0) folds every BatchNorm + ReLU into its convolution's output stage, so the
+        // 3x3 kernels and the narrow 1x1 kernel have fused instantiations too (the train step never reaches them: its fused launches are the
+        // 1x1 conv3 forwards and the masked conv1 data gradients, Cm >= 256 and K <= 512)
+        const bool halo_ok = narrow_k64 == 2 && a.Cm == 64 && a.g.Ck == 64 && a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && !a.g.sub &&
+                             (a.g.Wout == 16 || a.g.Wout == 32) && args.g.lhw >= 8 && a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == 64 &&
+                             a.g.row_pitch == a.g.Win * 64 && a.g.img_pitch == (long long)a.g.Hin * a.g.Win * 64 && a.P % 256 == 0;
+        const bool lean = !a.Res && !a.out_mask && !a.bits_out && !a.res_mask && !a.res_scale;      // scale / shift / bias / ReLU only: the EPI = 5 instantiations
+        if (halo_ok && lean) {
+            const int lds = (3 * 64 * 64 + HALO64_PX * 64) * 2;
+            DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_halo64_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+            const int tiles_n = a.P / 256;
+            hipLaunchKernelGGL((igemm_conv_halo64_kernel<3, 5>), dim3(tiles_n), dim3(512), lds, st, args, tiles_n);
+        } else if (narrow && lean) {
+            using Cfg = GemmCfg<64, 256, 1, 1, 1>;
+            const int tiles_m = (a.Cm + 63) / 64, tiles_n = (a.P + 255) / 256;
+            hipLaunchKernelGGL((igemm_conv_dma_kernel<64, 256, 3, 5>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(256), Cfg::LDS_BYTES / 2 * 3, st, args, tiles_m, tiles_n);
+        } else if (lean && k64 && cfg == CONV_128x256 && k64 != 6 && !a.g.sub) {
+            const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 255) / 256;
+            const int lds = (128 + 256) * 64 * 2 * 3;
+            DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+            hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 5>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        } else if (k64 && cfg == CONV_256x256) {
             const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
             hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
         } else if (cfg == CONV_128x256 || cfg == CONV_256x256) {
@@ -2768,13 +2797,13 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         DALI_ONCE_PER_DEVICE({
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         });
         if (a.X2) {
-            DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
-            hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, false, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+            DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+            hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 0, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         } else if (k64 == 6) hipLaunchKernelGGL((igemm_conv_k64_kernel<2, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(512), lds, st, args, tiles_m, tiles_n);
-        else if (lin) hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        else if (lin) hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 1>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
         else hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
     } else if (k64 && cfg == CONV_128) {
         const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.P + 127) / 128;
@@ -3086,6 +3115,22 @@ extern "C" int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, c
     IGemmArgs a{};
     a.W = w; a.X = x; a.O = y; a.Res = nullptr; a.in_scale = in_scale; a.in_shift = in_shift; a.stats = stats;
     a.Cm = cout; a.P = n * ho * wo; a.in_relu = in_relu;
+    fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
+    return launch_igemm_conv((hipStream_t)stream, a);
+}
+
+// y = relu?( conv(x) * out_scale[c] + out_shift[c] ): a convolution with the BatchNorm (+ ReLU) that follows it folded into the output stage
+// (the fp32 accumulators are scaled, shifted, clamped and rounded to bf16 once): the inference forward of every bottleneck's conv1 / conv2
+extern "C" int dali_conv2d_bn_act(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y, int n, int h, int wd, int cin, int cout,
+                                  int r, int s, int stride, int pad, const float* out_scale, const float* out_shift, int out_relu) {
+    DALI_REQUIRE(ctx && x && w && y && out_scale && out_shift, "dali_conv2d_bn_act: null argument");
+    DALI_REQUIRE(cin % 32 == 0 && cout % 8 == 0, "dali_conv2d_bn_act: cin must be a multiple of 32 and cout of 8 (cin=%d cout=%d)", cin, cout);
+    DALI_REQUIRE(stride == 1 || stride == 2, "dali_conv2d_bn_act: stride %d unsupported", stride);
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    IGemmArgs a{};
+    a.W = w; a.X = x; a.O = y;
+    a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu;
+    a.Cm = cout; a.P = n * ho * wo;
     fill_geom(a.g, n, h, wd, cin, ho, wo, r, s, stride, pad, 0);
     return launch_igemm_conv((hipStream_t)stream, a);
 }

@@ -128,6 +128,10 @@ int launch_bn_finalize(hipStream_t st, const float* partial, int tiles, int C, d
                        double* scratch);
 int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                           float* scale, float* shift);
+// many bn_eval_coeffs in one launch (kernel arguments hold the job table: at most BnEvalJobs::MAX jobs per launch)
+struct BnEvalJob { const float *gamma, *beta, *rm, *rv; float *scale, *shift; int C; };
+struct BnEvalJobs { static constexpr int MAX = 56; BnEvalJob job[MAX]; };
+int launch_bn_eval_coeffs_batched(hipStream_t st, const BnEvalJob* jobs, int n, float eps);
 int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,
                   const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y, uint8_t* mask_out);
 int bn_bwd_blocks(int P, int C, int* rows_per_block);

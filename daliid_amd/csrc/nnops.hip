@@ -62,6 +62,16 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
     shift[c] = beta[c] - rm[c] * sc;
 }
 
+// the same for many BatchNorms in one launch (the inference forward folds all of them into conv epilogues: 53 coefficient launches -> 2)
+__global__ void bn_eval_coeffs_batched_kernel(BnEvalJobs jobs, float eps) {
+    const BnEvalJob j = jobs.job[blockIdx.y];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < j.C; c += gridDim.x * blockDim.x) {
+        const float sc = j.gamma[c] / sqrtf(j.rv[c] + eps);
+        j.scale[c] = sc;
+        j.shift[c] = j.beta[c] - j.rm[c] * sc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block output: y = relu( raw*scale+shift + identity ), identity = idn (bf16) or raw2*scale2+shift2.
 // ------------------------------------------------------------------------------------------------
@@ -835,6 +845,17 @@ int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta,
                           float* scale, float* shift) {
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, rm, rv, eps, C, scale, shift);
     DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+int launch_bn_eval_coeffs_batched(hipStream_t st, const BnEvalJob* jobs, int n, float eps) {
+    for (int first = 0; first < n; first += BnEvalJobs::MAX) {
+        BnEvalJobs chunk;
+        const int m = n - first < BnEvalJobs::MAX ? n - first : BnEvalJobs::MAX;
+        int cmax = 1;
+        for (int i = 0; i < m; ++i) { chunk.job[i] = jobs[first + i]; cmax = chunk.job[i].C > cmax ? chunk.job[i].C : cmax; }
+        hipLaunchKernelGGL(bn_eval_coeffs_batched_kernel, dim3((cmax + 255) / 256, m), dim3(256), 0, st, chunk, eps);
+        DALI_LAUNCH_CHECK();
+    }
     return DALI_OK;
 }
 int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,

@@ -159,6 +159,9 @@ int bnlin_max_width() {
     if (v == -1) { const char* e = getenv("DALI_BNLIN_MAXW"); v = e ? atoi(e) : 512; }
     return v;
 }
+// inference forward with BatchNorm + ReLU folded into the convolutions' output stages (default); DALI_EVAL_FUSED=0 keeps the training dataflow
+// (raw output, then a bn_act pass) for A/B measurements and for tests of the unfused rounding points
+bool eval_fused() { return DALI_ENV_INT("DALI_EVAL_FUSED", 1) != 0; }
 // a cin = cout = w 1x1 convolution on the grid of conv3: the shape of the Gram GEMM a2^T a2 and of the second data-gradient GEMM
 Conv square_conv(const Conv& c3) {
     Conv q = c3;
@@ -388,9 +391,6 @@ extern "C" int dali_resnet_refresh_weights(dali_resnet* net, void* stream) {
 
 namespace {
 
-int bn_eval(dali_resnet* net, hipStream_t st, Bn& b) {
-    return launch_bn_eval_coeffs(st, net->P + b.g_off, net->P + b.b_off, net->B + b.rm_off, net->B + b.rv_off, 1e-5f, b.C, b.scale, b.shift);
-}
 int bn_train(dali_resnet* net, hipStream_t st, Bn& b, int tiles, double count) {
     return launch_bn_finalize(st, net->stat_partial, tiles, b.C, count, net->P + b.g_off, net->P + b.b_off, net->B + b.rm_off,
                               net->B + b.rv_off, 0.1f, 1e-5f, b.scale, b.shift, b.mean, b.invstd, net->red_scratch);
@@ -407,7 +407,19 @@ int conv_bn_fwd(dali_resnet* net, hipStream_t st, const Conv& c, Bn& out_bn, con
     int rc = launch_igemm_conv(st, a);
     if (rc) return rc;
     if (training) return bn_train(net, st, out_bn, igemm_conv_stat_tiles(a.Cm, a.P, a.g.R * a.g.S * a.g.Ck), (double)a.P);
-    return bn_eval(net, st, out_bn);
+    return DALI_OK;                                          // inference: the coefficients were formed at the top of the forward (one batched launch)
+}
+
+// inference: act = relu(bn(conv(x))) leaves the GEMM directly -- the running-statistics coefficients are known before the convolution runs, so
+// they ride in the fused output stage (IGemmArgs::out_scale / out_shift / out_relu) and neither the raw output nor a bn_act pass exists
+// (getFeatures.py:56-67 forwards the whole train set this way every epoch, train_encodersKIT.py:104-110; every validate, validateModels.py:38-39)
+int conv_bn_relu_eval(dali_resnet* net, hipStream_t st, const Conv& c, const Bn& bn, const uint16_t* x, uint16_t* act) {
+    IGemmArgs a{};
+    a.W = c.w_bf16; a.X = x; a.O = act;
+    a.out_scale = bn.scale; a.out_shift = bn.shift; a.out_relu = 1;
+    a.Cm = c.cout; a.P = net->N * c.hout * c.wout;
+    a.g = conv_geom(c, 0);
+    return launch_igemm_conv(st, a);
 }
 
 int conv_wgrad(dali_resnet* net, hipStream_t st, const Conv& c, const uint16_t* x, const Bn* in_bn, const uint16_t* dy) {
@@ -456,6 +468,13 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
     const bool tr = training != 0;
     net->fwd_training = tr;
     int rc;
+    if (!tr) {                                               // inference: every BatchNorm's scale / shift from the running statistics, one launch
+        std::vector<BnEvalJob> jobs;
+        auto add = [&](Bn& b) { jobs.push_back(BnEvalJob{net->P + b.g_off, net->P + b.b_off, net->B + b.rm_off, net->B + b.rv_off, b.scale, b.shift, b.C}); };
+        add(net->stem_bn);
+        for (auto& b : net->blocks) { add(b.b1); add(b.b2); add(b.b3); if (b.has_ds) add(b.bd); }
+        if ((rc = launch_bn_eval_coeffs_batched(st, jobs.data(), (int)jobs.size(), 1e-5f))) return rc;
+    }
     // ---- stem: conv1 -> bn1 -> (no ReLU) -> maxpool ----
     if ((rc = launch_stem_pack_image(st, images, net->N, net->H, net->W, net->ximg))) return rc;
     {
@@ -465,8 +484,7 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
         a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w;
         a.g = stem_geom(net);
         if ((rc = launch_igemm_conv(st, a))) return rc;
-        rc = tr ? bn_train(net, st, net->stem_bn, igemm_conv_stat_tiles(a.Cm, a.P, 224), (double)a.P) : bn_eval(net, st, net->stem_bn);
-        if (rc) return rc;
+        if (tr && (rc = bn_train(net, st, net->stem_bn, igemm_conv_stat_tiles(a.Cm, a.P, 224), (double)a.P))) return rc;
     }
     if ((rc = launch_maxpool_bn_fwd(st, net->raw0, net->stem_bn.scale, net->stem_bn.shift, net->N, net->stem_h, net->stem_w, net->stem.cout,
                                     net->pool0, net->pool_arg))) return rc;
@@ -475,10 +493,15 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
     for (auto& b : net->blocks) {
         b.x = const_cast<uint16_t*>(x);
         const size_t e1 = (size_t)net->N * b.hin * b.win * b.width, e2 = (size_t)net->N * b.hout * b.wout * b.width;
-        if ((rc = conv_bn_fwd(net, st, b.c1, b.b1, x, nullptr, b.raw1, tr))) return rc;
-        if ((rc = launch_bn_act(st, b.raw1, b.b1.scale, b.b1.shift, nullptr, nullptr, nullptr, nullptr, 1, e1, b.width, b.a1, nullptr))) return rc;
-        if ((rc = conv_bn_fwd(net, st, b.c2, b.b2, b.a1, nullptr, b.raw2, tr))) return rc;
-        if ((rc = launch_bn_act(st, b.raw2, b.b2.scale, b.b2.shift, nullptr, nullptr, nullptr, nullptr, 1, e2, b.width, b.a2, nullptr))) return rc;
+        if (!tr && eval_fused()) {
+            if ((rc = conv_bn_relu_eval(net, st, b.c1, b.b1, x, b.a1))) return rc;
+            if ((rc = conv_bn_relu_eval(net, st, b.c2, b.b2, b.a1, b.a2))) return rc;
+        } else {
+            if ((rc = conv_bn_fwd(net, st, b.c1, b.b1, x, nullptr, b.raw1, tr))) return rc;
+            if ((rc = launch_bn_act(st, b.raw1, b.b1.scale, b.b1.shift, nullptr, nullptr, nullptr, nullptr, 1, e1, b.width, b.a1, nullptr))) return rc;
+            if ((rc = conv_bn_fwd(net, st, b.c2, b.b2, b.a1, nullptr, b.raw2, tr))) return rc;
+            if ((rc = launch_bn_act(st, b.raw2, b.b2.scale, b.b2.shift, nullptr, nullptr, nullptr, nullptr, 1, e2, b.width, b.a2, nullptr))) return rc;
+        }
         const size_t elems = (size_t)net->N * b.hout * b.wout * b.cout;
         if (b.lin3) {
             // bn3's batch statistics from the moments of a2 (bnlin.hip), then conv3 writes y = relu(bn3(conv3(a2)) + x) and its ReLU mask itself
@@ -497,7 +520,7 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                 if ((rc = launch_bnlin_stats(st, b.c3.wt_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
                                              net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.ut, b.dot, b.b3.scale, b.b3.shift, b.b3.mean,
                                              b.b3.invstd))) return rc;
-            } else if ((rc = bn_eval(net, st, b.b3))) return rc;
+            }
             IGemmArgs a{};
             a.W = b.c3.w_bf16; a.X = b.a2; a.O = b.y; a.Res = x; a.out_scale = b.b3.scale; a.out_shift = b.b3.shift; a.out_relu = 1;
             if (b.has_ds) {                               // identity = bnd(convd(x)): raw output + its BatchNorm as residual scale / extra shift

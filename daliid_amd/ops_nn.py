@@ -29,6 +29,19 @@ def conv2d_fwd(x, w, stride=1, pad=0, in_scale=None, in_shift=None, in_relu=Fals
     return (y, stats) if want_stats else y
 
 
+def conv2d_bn_act(x, w, scale, shift, stride=1, pad=0, relu=True):
+    """y = relu?(conv(x) * scale[c] + shift[c]) in ONE launch: x [N,H,W,Cin] bf16, w [Cout,R,S,Cin] bf16, scale / shift fp32 [Cout] -> y bf16
+    (dali_conv2d_bn_act: the inference forward of a bottleneck's conv + BatchNorm + ReLU, the affine applied to the fp32 accumulators)."""
+    n, h, wd, cin = x.shape
+    cout, r, s, _ = w.shape
+    ho, wo = _out_hw(h, wd, r, s, stride, pad)
+    y = torch.empty(n, ho, wo, cout, device=x.device, dtype=bf16)
+    _lib.check(_lib.lib().dali_conv2d_bn_act(_lib.ctx(x.device), _lib.stream_ptr(), _lib.ptr(x, bf16, "x"), _lib.ptr(w, bf16, "w"), _lib.ptr(y),
+                                              n, h, wd, cin, cout, r, s, stride, pad, _lib.ptr(scale, torch.float32, "scale"),
+                                              _lib.ptr(shift, torch.float32, "shift"), int(relu)), "dali_conv2d_bn_act")
+    return y
+
+
 def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, residual=None, inplace=False, residual_mask=None):
     """dy [N,Ho,Wo,Cout] bf16, wt [Cin,R,S,Cout] bf16 -> dx [N,H,W,Cin] bf16 (+ residual).  ``inplace``: accumulate into
     ``residual`` itself (residual == dx; what the net plan does for the downsample branch).  ``residual_mask``: uint8

@@ -144,6 +144,12 @@ int dali_rank_shard_finish(dali_ctx* ctx, void* stream, const int32_t* bins, con
 int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y,
                     int n, int h, int wd, int cin, int cout, int r, int s, int stride, int pad,
                     const float* in_scale, const float* in_shift, int in_relu, float* stats);
+/* y = relu?( conv(x) * out_scale[c] + out_shift[c] ): the convolution with the BatchNorm (+ ReLU) that follows it folded into the GEMM's output
+ * stage -- the fp32 accumulators are scaled, shifted, clamped and rounded to bf16 once; no raw output, no separate BatchNorm pass.  The inference
+ * forward of torchvision's Bottleneck conv1 / conv2 (under Encoders.py:336-339) with scale = gamma / sqrt(running_var + eps),
+ * shift = beta - running_mean * scale (getFeatures.py:56-67 forwards in eval mode).  cin % 32 == 0, cout % 8 == 0, stride 1 or 2. */
+int dali_conv2d_bn_act(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y, int n, int h, int wd, int cin, int cout,
+                       int r, int s, int stride, int pad, const float* out_scale, const float* out_shift, int out_relu);
 /* 1x1 convolution (a [pixels][cin] x [cout][cin]^T GEMM) with the fused output stage:
  *   y = gate_{out_mask}( relu?( acc * out_scale[c] + out_shift[c] + bias[c] + res_scale[c] * residual ) ),  bits_out = (y > 0), 1 bit per
  *   element (res_scale: the downsample branch's BatchNorm scale when the residual is its raw convolution output).

@@ -103,6 +103,9 @@ def forward_matched(model, x, training=True):
     """model: oracle.resnet50_reid.ResNet50ReID (its parameters receive the gradients).  training=True: batch statistics (the train
     step); False: running statistics (extractFeatures), same rounding points."""
     _bn = _bn_train if training else _bn_eval
+    # inference (dali_resnet_forward, training = 0): bn1 / bn2 + ReLU ride in their convolution's output stage, i.e. they act on the fp32
+    # accumulators and a1 / a2 are the only tensors stored (conv_bn_relu_eval, resnet_plan.hip); training stores the raw outputs in bf16
+    Qr = Q if training else (lambda t: t)
     x = Q(x)
     u = _conv(x, model.conv1)
     z = _bn(u, Q(u), model.bn1)                   # no ReLU after the stem BN (Encoders.py:334)
@@ -111,9 +114,9 @@ def forward_matched(model, x, training=True):
     for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
         for blk in layer:
             u1 = _conv(x, blk.conv1)
-            a1 = Q(F.relu(_bn(u1, Q(u1), blk.bn1)))
+            a1 = Q(F.relu(_bn(u1, Qr(u1), blk.bn1)))
             u2 = _conv(a1, blk.conv2)
-            a2 = Q(F.relu(_bn(u2, Q(u2), blk.bn2)))
+            a2 = Q(F.relu(_bn(u2, Qr(u2), blk.bn2)))
             u3 = _conv(a2, blk.conv3)
             # where conv3's output is never stored (csrc/bnlin.hip) bn3 acts on the fp32 accumulators
             out = _bn(u3, Q(u3) if stores_raw3(blk) else u3, blk.bn3)

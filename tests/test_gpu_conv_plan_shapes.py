@@ -67,6 +67,15 @@ def test_plan_conv_exact_at_batch_256(nn, case):
     assert torch.equal(yk.cpu(), ref_y.to(bf16)), (yk.cpu().float() - ref_y).abs().max()
     assert torch.equal(stats.double().sum(0)[:, 0].cpu(), ref_y.double().sum((0, 1, 2)))       # integer sums: exact in any order
     del yk, stats
+    # the inference forward's launch of the same convolution: BatchNorm scale / shift + ReLU applied to the fp32 accumulators in the output stage
+    # (dali_conv2d_bn_act; the 3x3 and the 64-channel kernels have their own fused instantiations).  Power-of-two scales and integer shifts keep
+    # acc * scale + shift exact in fp32, so the result is the oracle's value rounded once to bf16, bit for bit.
+    scale = torch.tensor([0.5, 1.0, 2.0, 0.25])[torch.randint(0, 4, (cout,), generator=gen)]
+    shift = torch.randint(-3, 4, (cout,), generator=gen).float()
+    ya = nn.conv2d_bn_act(xg, w_fwd, scale.cuda(), shift.cuda(), stride, pad, relu=True)
+    ref_a = (ref_y * scale + shift).clamp_min(0)
+    assert torch.equal(ya.cpu(), ref_a.to(bf16)), (ya.cpu().float() - ref_a).abs().max()
+    del ya
     # data gradient with the identity path's masked residual (dy * (y > 0) formed in the epilogue)
     ref_dx = nhwc(x.grad)
     res = _ints((N, h, w, cin), gen)

@@ -240,13 +240,11 @@ def test_side_stream_finish_beside_workspace_users_of_the_main_stream(T):
     adam(p, m, v, sq_solo)
     torch.cuda.synchronize()
     for rep in range(4):
-        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         sqs = [torch.zeros(1, device=dev) for _ in range(6)]
         ticket = T.submit(plan, decode=lambda f: imgs[int(f.split("/")[-1])])
         torch.cuda.synchronize()
         for i in range(3):
-            pi = p.clone() if i else p
-            adam(pi, m.clone(), v.clone(), sqs[i])
+            adam(p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), sqs[i])
         got = T.finish(ticket, dev, side_stream=True)                       # enqueued while the Adam launches above are still running
         for i in range(3, 6):
             adam(p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), sqs[i])
