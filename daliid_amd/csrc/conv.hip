@@ -1485,6 +1485,10 @@ __global__ __launch_bounds__(512, 4) void igemm_conv_halo64_kernel(IGemmArgs a, 
     conv_epilogue_g<TM, TN, FM, FN, 4, NT, (EPI == 3 || EPI == 5) ? EPI : 2>(a, acc, 0, tn, smem, 0, wn);
 }
 
+}  // namespace dali
+#include "fused1x1.h"
+namespace dali {
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: M = Cm (channels of dY), N = R*S*Ck, K = pixels.  Both operands are stored pixel-major, so the
 // MFMA fragments (8 consecutive k per lane) are produced by ds_read_b64_tr_b16 transposing reads.
@@ -2721,6 +2725,44 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         // the inference forward (dali_resnet_forward, training = 0) folds every BatchNorm + ReLU into its convolution's output stage, so the
         // 3x3 kernels and the narrow 1x1 kernel have fused instantiations too (the train step never reaches them: its fused launches are the
         // 1x1 conv3 forwards and the masked conv1 data gradients, Cm >= 256 and K <= 512)
+        // short-K 1x1 with a residual / mask stream: the persistent streaming kernel (fused1x1.h).  K <= 256: at K = 512 (layer4) its four ring
+        // producers cannot issue the 32 DMA pieces of a k-step as fast as the consumers multiply it (141 against 125 us; the block is capped at 16 waves)
+        if (DALI_ENV_INT("DALI_CONV_PERSIST", 1) != 0 && a.g.R == 1 && a.g.S == 1 && a.g.stride == 1 && a.g.pad == 0 && !a.g.sub && !a.X2 && !a.res_mask &&
+            (a.Cm % F1_TM) == 0 && (a.g.Ck & 63) == 0 && a.g.Ck <= DALI_ENV_INT("DALI_CONV_PERSIST_KMAX", 256) && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck &&
+            a.g.img_pitch == (long long)a.g.Hin * a.g.Win * a.g.Ck && a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout &&
+            (long long)a.P * a.Cm * 2 < 0x7ff00000ll && (a.Res || a.out_mask || a.bits_out)) {
+            static int n_cus = 0;
+            if (!n_cus) {
+                int dev = 0, v = 0;
+                DALI_HIP(hipGetDevice(&dev));
+                DALI_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+                n_cus = v > 8 ? v & ~7 : 8;
+            }
+            const int tiles_m = a.Cm / F1_TM, tiles_n = (a.P + F1_TN - 1) / F1_TN;
+            if ((long long)tiles_m * tiles_n >= 2ll * n_cus && (n_cus / 8) % tiles_m == 0) {     // (every workgroup keeps one channel tile)
+                const dim3 f1_block((F1_NC + F1_NP + F1_NR) * 64);
+#define DALI_F1_LAUNCH(RES, OM, BITS)                                                                                                                     \
+    do {                                                                                                                                                  \
+        DALI_ONCE_PER_DEVICE({                                                                                                                            \
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<2, 2, RES, OM, BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(2, 2))); \
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<3, 1, RES, OM, BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(3, 1))); \
+        });                                                                                                                                               \
+        if (a.g.Ck <= 128) hipLaunchKernelGGL((fused1x1_persist_kernel<2, 2, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(2, 2), st, args, tiles_m, tiles_n); \
+        else hipLaunchKernelGGL((fused1x1_persist_kernel<3, 1, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(3, 1), st, args, tiles_m, tiles_n); \
+    } while (0)
+                const bool f_res = a.Res != nullptr, f_om = a.out_mask != nullptr, f_bits = a.bits_out != nullptr;
+                if (f_res && !f_om && f_bits) DALI_F1_LAUNCH(true, false, true);          // conv3 forward of the train step
+                else if (f_res && !f_om && !f_bits) DALI_F1_LAUNCH(true, false, false);   // conv3 forward, inference
+                else if (f_res && f_om && !f_bits) DALI_F1_LAUNCH(true, true, false);     // conv1 data gradient + identity gradient, masked
+                else if (!f_res && f_om && !f_bits) DALI_F1_LAUNCH(false, true, false);   // masked data gradient without a residual
+                else if (f_res && f_om && f_bits) DALI_F1_LAUNCH(true, true, true);
+                else if (!f_res && f_om && f_bits) DALI_F1_LAUNCH(false, true, true);
+                else DALI_F1_LAUNCH(false, false, true);
+#undef DALI_F1_LAUNCH
+                DALI_LAUNCH_CHECK();
+                return DALI_OK;
+            }
+        }
         const bool halo_ok = narrow_k64 == 2 && a.Cm == 64 && a.g.Ck == 64 && a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && !a.g.sub &&
                              (a.g.Wout == 16 || a.g.Wout == 32) && args.g.lhw >= 8 && a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == 64 &&
                              a.g.row_pitch == a.g.Win * 64 && a.g.img_pitch == (long long)a.g.Hin * a.g.Win * 64 && a.P % 256 == 0;

@@ -1,0 +1,7 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_bnlin.py tests/test_gpu_resnet_blocks.py tests/test_gpu_e2e_parity.py tests/test_gpu_trainer.py tests/test_gpu_resnet.py -q -m gpu -x > gpurun_out/r5d_tests.log 2>&1
+rc=$?; echo "pytest rc=$rc"; tail -n 5 gpurun_out/r5d_tests.log
+[ $rc -ne 0 ] && exit $rc
+bash scripts/ab_env.sh 3 "DALI_CONV_PERSIST=0" "DALI_CONV_PERSIST=1" || exit 124
+for f in 0 1 0 1; do DALI_CONV_PERSIST=$f timeout -k 10 120 python scripts/time_eval_forward.py 500 20 || exit 124; done

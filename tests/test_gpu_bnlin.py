@@ -79,6 +79,49 @@ def test_conv1x1_fused_masked_gradient_stage(nn, P, cin, cout):
     ulp_close(y3, (x.float() @ w.float().T + bias) * keep, 1.5)
 
 
+# The persistent streaming kernel (csrc/fused1x1.h) takes these launches when they have >= 2 tiles of 128 x 128 per CU: the plan's own conv3 /
+# masked conv1 gradient shapes at batch 256, a ragged pixel count (edge tile: predicated stores, zero-filled operand rows) and an inference
+# batch (500 images: 62.5 pixel tiles per XCD).  Small integers: every product, sum, power-of-two scale and integer shift is exact in fp32,
+# so the result is the reference rounded once to bf16 -- bit for bit, mask bits included.
+@pytest.mark.parametrize("P,cin,cout", [(524288, 64, 256), (131072, 128, 512), (32768, 256, 1024), (32768, 512, 2048), (65000, 64, 256),
+                                        (64000, 256, 1024), (40037, 128, 256), (33000, 512, 1024)])
+def test_conv1x1_fused_streaming_kernel_exact_integers(nn, P, cin, cout):
+    g = torch.Generator().manual_seed(P + cin + cout + 3)
+    dev = "cuda"
+    x = torch.randint(-2, 3, (P, cin), generator=g).to(dev)
+    w = torch.randint(-1, 2, (cout, cin), generator=g).to(dev)
+    res = torch.randint(-3, 4, (P, cout), generator=g, dtype=torch.int8).to(dev)
+    scale = torch.tensor([0.5, 1.0, 2.0, 0.25])[torch.randint(0, 4, (cout,), generator=g)].to(dev)
+    shift = torch.randint(-3, 4, (cout,), generator=g).float().to(dev)
+    rs = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (cout,), generator=g)].to(dev)
+    rb = torch.randint(-2, 3, (cout,), generator=g).float().to(dev)
+    acc = x.float() @ w.float().T                                                   # exact: |acc| <= 2 * 512
+    xb, wb, resb = x.to(bf16), w.to(bf16), res.to(bf16)
+    # forward use: y = relu(acc * scale + shift + residual), mask bits of the stored tensor
+    y, bits = nn.conv1x1_fused(xb, wb, out_scale=scale, out_shift=shift, residual=resb, relu=True, want_bits=True)
+    ref = torch.relu(acc * scale + shift + res.float()).to(bf16)
+    assert torch.equal(y, ref), (y.float() - ref.float()).abs().max()
+    assert torch.equal(bits, bits_of(ref))
+    del y, bits
+    # a downsample block: the residual is another BatchNorm's raw input (res_scale * residual + bias)
+    y3 = nn.conv1x1_fused(xb, wb, out_scale=scale, out_shift=shift, bias=rb, residual=resb, res_scale=rs, relu=True)
+    assert torch.equal(y3, torch.relu(acc * scale + shift + rb + rs * res.float()).to(bf16))
+    del y3
+    # backward use: out = (acc + residual) gated by the mask bits, also in place over the residual
+    keep = torch.rand(P, cout, generator=g).to(dev) > 0.4
+    mask = bits_of(keep.float())
+    ref_g = ((acc + res.float()) * keep).to(bf16)
+    yg = nn.conv1x1_fused(xb, wb, residual=resb, out_mask=mask)
+    assert torch.equal(yg, ref_g)
+    buf = resb.clone()
+    yi = nn.conv1x1_fused(xb, wb, residual=buf, out_mask=mask, inplace=True)
+    assert yi.data_ptr() == buf.data_ptr() and torch.equal(yi, ref_g)
+    del yg, yi, buf
+    # mask without a residual (the merged data gradients of the Gram-scheme blocks hand on a masked result)
+    ym = nn.conv1x1_fused(xb, wb, bias=rb, out_mask=mask)
+    assert torch.equal(ym, ((acc + rb) * keep).to(bf16))
+
+
 def hard_case(P, C, w, seed):
     """Inputs at the sizes the net plan USES the scheme at (layer1: P = 524288, w = 64; layer2: P = 131072, w = 128 at batch 256) and the
     w >= 512 shape whose column sums come from (split, n tile) rows, with heavy cancellation in var = E[raw^2] - mean^2: activations with
