@@ -6,6 +6,7 @@ import numpy as np, torch
 from daliid_amd import _lib, ops_nn as nn
 bf16 = torch.bfloat16
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+os.environ.setdefault("DALI_CONV_PERSIST_KMAX", "512")            # the diagnostic covers layer4 too (the plan keeps it on the tile-per-workgroup kernel)
 L = _lib.lib(); L.dali_debug_set_conv_stamps.argtypes = [ctypes.c_void_p]
 for name, P, K, Cm in [("layer1", B * 2048, 64, 256), ("layer2", B * 512, 128, 512), ("layer3", B * 128, 256, 1024), ("layer4", B * 128, 512, 2048)]:
     x = torch.randn(P, K, device="cuda").to(bf16); w = (torch.randn(Cm, K, device="cuda") / K ** 0.5).to(bf16)
