@@ -51,6 +51,7 @@ struct Block {
     bool lin_ds = false;
     float *gram_d = nullptr, *m2_d = nullptr, *ut_d = nullptr, *bvec_d = nullptr, *qk_d = nullptr;   // [cin][cin], [cin], [cin][cout], [cin], [2][cout]
     uint16_t* wdd = nullptr;                                   // [cin][cout + cin]: (A_d.Wd)^T beside -(Wd^T diag(Q_d) Wd)
+    uint16_t* dbg_d_raw1 = nullptr;                            // where the last backward of this block left d(raw1) (scratch: valid until the next block runs)
 };
 
 struct Arena {
@@ -642,6 +643,7 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
     BnBwdSide s1{b.raw1, b.b1.mean, b.b1.invstd, b.b1.scale, b.b1.shift};
     if ((rc = launch_bn_bwd(st, d_a1, nullptr, nullptr, s1, nullptr, 1, Pin, b.width, net->bwd_partial, b.b1.coef, nullptr, net->G + b.b1.g_off,
                             net->G + b.b1.b_off, nullptr, nullptr, d_a1, nullptr, nullptr, net->red_scratch))) return rc;
+    b.dbg_d_raw1 = d_a1;
     // conv1 (+ identity / downsample branch); the result is masked with the previous block's ReLU bits
     if ((rc = conv_wgrad(net, st, b.c1, b.x, nullptr, d_a1))) return rc;
     uint16_t* dx = d_a2;                                          // d_a2 is dead now
@@ -670,6 +672,23 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
     return DALI_OK;
 }
 
+// maxpool + stem BN backward, then the stem weight gradient (no data gradient: images need none)
+static int stem_backward(dali_resnet* net, hipStream_t st) {
+    int rc;
+    uint16_t* d_raw0 = next_gbuf(net, net->cur_dy);
+    if ((rc = launch_maxpool_bn_bwd(st, net->cur_dy, net->pool_arg, net->raw0, net->stem_bn.mean, net->stem_bn.invstd, net->stem_bn.scale,
+                                    net->N, net->stem_h, net->stem_w, net->stem.cout, net->bwd_partial, net->stem_bn.coef,
+                                    net->G + net->stem_bn.g_off, net->G + net->stem_bn.b_off, d_raw0, net->red_scratch))) return rc;
+    WGradArgs a{};
+    a.dY = d_raw0; a.X = net->ximg; a.partial = net->wgrad_slab; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
+    a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w; a.Ntot = 224;
+    a.g = stem_geom(net);
+    size_t wsb;
+    wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb, 7);
+    if ((rc = launch_igemm_wgrad(st, a, net->stem_dw_pad, 0))) return rc;
+    return launch_stem_unpack_wgrad(st, net->stem_dw_pad, net->stem.cout, net->G + net->stem.w_off);
+}
+
 // Runs stages [stage_begin, stage_end] of the backward pass (0: neck+head+layer4, 1: layer3, 2: layer2,
 // 3: layer1+stem).  Stage 0 consumes d_emb; later stages continue from the gradient the previous call left.
 extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float* d_emb, int stage_begin, int stage_end) {
@@ -691,22 +710,32 @@ extern "C" int dali_resnet_backward(dali_resnet* net, void* stream, const float*
         }
         for (int bi = net->stage_last[li]; bi >= net->stage_first[li]; --bi)
             if ((rc = block_backward(net, st, net->blocks[bi], bi > 0 ? net->blocks[bi - 1].ybits : nullptr))) return rc;
-        if (stage == 3) {
-            // maxpool + stem BN backward, then the stem weight gradient (no data gradient: images need none)
-            uint16_t* d_raw0 = next_gbuf(net, net->cur_dy);
-            if ((rc = launch_maxpool_bn_bwd(st, net->cur_dy, net->pool_arg, net->raw0, net->stem_bn.mean, net->stem_bn.invstd, net->stem_bn.scale,
-                                            net->N, net->stem_h, net->stem_w, net->stem.cout, net->bwd_partial, net->stem_bn.coef,
-                                            net->G + net->stem_bn.g_off, net->G + net->stem_bn.b_off, d_raw0, net->red_scratch))) return rc;
-            WGradArgs a{};
-            a.dY = d_raw0; a.X = net->ximg; a.partial = net->wgrad_slab; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
-            a.Cm = net->stem.cout; a.P = net->N * net->stem_h * net->stem_w; a.Ntot = 224;
-            a.g = stem_geom(net);
-            size_t wsb;
-            wgrad_plan(a.Cm, a.Ntot, a.P, 512, &a.splits, &a.pix_per_split, &wsb, 7);
-            if ((rc = launch_igemm_wgrad(st, a, net->stem_dw_pad, 0))) return rc;
-            if ((rc = launch_stem_unpack_wgrad(st, net->stem_dw_pad, net->stem.cout, net->G + net->stem.w_off))) return rc;
-        }
+        if (stage == 3 && (rc = stem_backward(net, st))) return rc;
     }
+    return DALI_OK;
+}
+
+// Diagnostic (include/daliid_debug.h): the backward pass ONE bottleneck at a time, so that a test can read the gradient entering every block
+// (`grad_cur` of dali_resnet_debug_tensor) instead of one per stage.  Call with block = last block first (that call also runs the neck + head
+// backward from d_emb), then block - 1, ... down to 0, then -1 (the stem); same launches, same order as dali_resnet_backward.
+extern "C" int dali_debug_resnet_backward_block(dali_resnet* net, void* stream, const float* d_emb, int block) {
+    DALI_REQUIRE(net && net->P && net->G, "dali_debug_resnet_backward_block: net not bound (grads required)");
+    DALI_REQUIRE(net->fwd_training, "dali_debug_resnet_backward_block: the last forward was not in training mode");
+    const int nb = (int)net->blocks.size();
+    if (block == -1) return stem_backward(net, (hipStream_t)stream);      // after block 0: the stem (its own call, so that block 0's scratch tensors can be read first)
+    DALI_REQUIRE(block >= 0 && block < nb, "dali_debug_resnet_backward_block: block %d out of range", block);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (block == nb - 1) {
+        DALI_REQUIRE(d_emb != nullptr, "dali_debug_resnet_backward_block: d_emb is null");
+        if ((rc = launch_bn1d_bwd(st, net->feat, d_emb, net->N, net->feat_dim, net->P + net->neck.g_off, net->neck_mean, net->neck_invstd, net->dfeat,
+                                  net->G + net->neck.g_off, net->G + net->neck.b_off))) return rc;
+        net->cur_dy = net->gbuf[0];
+        if ((rc = launch_head_pool_bwd(st, net->dfeat, net->head_arg, net->N, net->head_hw, net->feat_dim, net->feature_mode, net->cur_dy,
+                                       net->blocks.back().ybits))) return rc;
+        net->cur_dy_bytes = (int64_t)net->N * net->head_hw * net->feat_dim * 2;
+    }
+    if ((rc = block_backward(net, st, net->blocks[block], block > 0 ? net->blocks[block - 1].ybits : nullptr))) return rc;
     return DALI_OK;
 }
 
@@ -740,6 +769,7 @@ extern "C" int dali_resnet_debug_tensor(dali_resnet* net, const char* name, void
                 if (f == "raw3" && !b.lin3) { *ptr = b.raw3; *bytes = (int64_t)(pout * b.cout * 2); return DALI_OK; }
                 if (f == "rawd" && b.has_ds) { *ptr = b.rawd; *bytes = (int64_t)(pout * b.cout * 2); return DALI_OK; }
                 if (f == "y") { *ptr = b.y; *bytes = (int64_t)(pout * b.cout * 2); return DALI_OK; }
+                if (f == "d_raw1" && b.dbg_d_raw1) { *ptr = b.dbg_d_raw1; *bytes = (int64_t)(pin * b.width * 2); return DALI_OK; }
                 if (f.rfind("bn", 0) == 0 && f.size() > 4) {
                     Bn* bn = f[2] == '1' ? &b.b1 : f[2] == '2' ? &b.b2 : f[2] == '3' ? &b.b3 : (f[2] == 'd' && b.has_ds) ? &b.bd : nullptr;
                     if (bn && bn_field(*bn, f.substr(4))) return DALI_OK;

@@ -24,6 +24,12 @@ int dali_debug_wgrad_splits(int Cm, int Ntot, int P, int taps, int halo_w);
 /* the split-K reduce alone: out[e] (+)= sum_k partial[k][e], fixed order (tests/test_gpu_conv.py, scripts/bench_reduce.py) */
 int dali_debug_splitk_reduce(void* stream, const float* partial, float* out, long long elems, int splits, int accumulate);
 
+/* the ResNet plan's backward ONE bottleneck at a time (last block first: that call also runs the neck + head backward from d_emb; after
+ * block 0, block = -1 runs the stem), so that a test can read the gradient entering every block (`grad_cur` of dali_resnet_debug_tensor); same launches
+ * in the same order as dali_resnet_backward (tests/test_gpu_resnet_blocks.py, the batch-256 composition check) */
+struct dali_resnet;
+int dali_debug_resnet_backward_block(struct dali_resnet* net, void* stream, const float* d_emb, int block);
+
 #ifdef __cplusplus
 }
 #endif

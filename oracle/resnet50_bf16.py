@@ -87,6 +87,49 @@ def ds_through_moments(blk, first_of_net):
     return (first_of_net and d is not None and d[0].stride == (1, 1) and d[0].in_channels % 32 == 0 and d[0].in_channels <= 128 and not stores_raw3(blk))
 
 
+class _Conv3Bn3Moments(torch.autograd.Function):
+    """conv3 (1x1) + training-mode bn3 of a bottleneck whose BatchNorm runs through the moments of conv3's input (csrc/bnlin.hip; every block of
+    ResNet-50 by default).  Forward: bn3 on the fp32 accumulators (raw3 is never stored).  Backward, as the plan forms it (resnet_plan.hip
+    block_backward, launch_bnlin_bwd): with dz the masked gradient of the block output, m_b = mean(dz), m_g = mean(dz xhat),
+        d_raw3 = A dz - Kc - Qc raw3,   A = scale,  Qc = scale invstd m_g,  Kc = scale (m_b - mean invstd m_g)
+        d_a2   = dz (A.W3) - Kc W3 - a2 (W3^T diag(Qc) W3)
+    where the two matrices (A.W3)^T and W3^T diag(Qc) W3 are WEIGHT IMAGES OF THE DATA-GRADIENT GEMM, i.e. rounded to bf16 after the fp32
+    coefficients were folded in.  That second rounding is a coherent 2^-9 perturbation of the backward map (every pixel sees the same perturbed
+    matrix), which plain autograd through bf16(W3) does not have; the weight gradients of the convolutions below -- small residuals of large sums --
+    pick it up in full (layer1.0 conv1.weight at batch 256: 5.7e-2 against a twin without it).  dW3, gamma', beta' stay fp32 as in the plan."""
+
+    @staticmethod
+    def forward(ctx, a2, w, gamma, beta, eps):
+        wq = w.to(torch.bfloat16).float()
+        u = F.conv2d(a2, wq)
+        mean = u.mean((0, 2, 3))
+        var = u.var((0, 2, 3), unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + eps)
+        ctx.save_for_backward(a2, wq, gamma, u, mean, invstd)
+        sh = (1, -1, 1, 1)
+        return (u - mean.view(sh)) * (gamma * invstd).view(sh) + beta.view(sh)
+
+    @staticmethod
+    def backward(ctx, dz):
+        a2, wq, gamma, u, mean, invstd = ctx.saved_tensors
+        sh = (1, -1, 1, 1)
+        P = u.numel() / u.shape[1]
+        xhat = (u - mean.view(sh)) * invstd.view(sh)
+        d_beta = dz.sum((0, 2, 3))
+        d_gamma = (dz * xhat).sum((0, 2, 3))
+        scale = gamma * invstd
+        d_raw = scale.view(sh) * (dz - (d_beta / P).view(sh) - xhat * (d_gamma / P).view(sh))
+        dw = torch.nn.grad.conv2d_weight(a2, wq.shape, d_raw)                       # fp32, as the plan's G0-based form up to summation order
+        w2 = wq.flatten(1)                                                          # [C, width]
+        Qc = scale * invstd * d_gamma / P
+        Kc = scale * (d_beta / P - mean * invstd * d_gamma / P)
+        m1 = (scale.view(-1, 1) * w2).to(torch.bfloat16).float()                    # (A.W3): rounded once more as a GEMM operand image
+        m2 = (w2.t() @ (Qc.view(-1, 1) * w2)).to(torch.bfloat16).float()            # W3^T diag(Qc) W3 [width, width], likewise
+        bvec = w2.t() @ Kc                                                          # fp32 bias of the merged GEMM
+        d_a2 = torch.einsum("nchw,ck->nkhw", dz, m1) - torch.einsum("nkhw,kj->njhw", a2, m2) - bvec.view(sh)
+        return d_a2, dw, d_gamma, d_beta, None
+
+
 def _conv(x, conv):
     return F.conv2d(x, QW(conv.weight), stride=conv.stride, padding=conv.padding)
 
@@ -117,9 +160,12 @@ def forward_matched(model, x, training=True):
             a1 = Q(F.relu(_bn(u1, Qr(u1), blk.bn1)))
             u2 = _conv(a1, blk.conv2)
             a2 = Q(F.relu(_bn(u2, Qr(u2), blk.bn2)))
-            u3 = _conv(a2, blk.conv3)
-            # where conv3's output is never stored (csrc/bnlin.hip) bn3 acts on the fp32 accumulators
-            out = _bn(u3, Q(u3) if stores_raw3(blk) else u3, blk.bn3)
+            if training and not stores_raw3(blk):
+                out = _Conv3Bn3Moments.apply(a2, blk.conv3.weight, blk.bn3.weight, blk.bn3.bias, 1e-5)
+            else:
+                u3 = _conv(a2, blk.conv3)
+                # where conv3's output is never stored (csrc/bnlin.hip) bn3 acts on the fp32 accumulators
+                out = _bn(u3, Q(u3) if stores_raw3(blk) else u3, blk.bn3)
             if blk.downsample is not None:
                 ud = _conv(x, blk.downsample[0])
                 idn = _bn(ud, (QF if ds_through_moments(blk, first) else Q)(ud), blk.downsample[1])

@@ -27,10 +27,13 @@ def rel_l2(a, b):
 def block_forward_matched(blk, x):
     u1 = M._conv(x, blk.conv1); a1 = M.Q(F.relu(M._bn_train(u1, M.Q(u1), blk.bn1)))
     u2 = M._conv(a1, blk.conv2); a2 = M.Q(F.relu(M._bn_train(u2, M.Q(u2), blk.bn2)))
-    u3 = M._conv(a2, blk.conv3)
-    # narrow blocks without a downsample branch never store conv3's output (bn3 through the moments of a2, csrc/bnlin.hip): bn3 acts on the
-    # fp32 accumulators there; elsewhere raw3 is stored in bf16 as before
-    out = M._bn_train(u3, M.Q(u3) if M.stores_raw3(blk) else u3, blk.bn3)
+    # blocks whose bn3 runs through the moments of a2 (csrc/bnlin.hip) never store conv3's output: bn3 acts on the fp32 accumulators and the
+    # backward uses the merged bf16 weight images (oracle _Conv3Bn3Moments); elsewhere raw3 is stored in bf16 as before
+    if not M.stores_raw3(blk):
+        out = M._Conv3Bn3Moments.apply(a2, blk.conv3.weight, blk.bn3.weight, blk.bn3.bias, 1e-5)
+    else:
+        u3 = M._conv(a2, blk.conv3)
+        out = M._bn_train(u3, M.Q(u3), blk.bn3)
     if blk.downsample is not None:
         ud = M._conv(x, blk.downsample[0]); idn = M._bn_train(ud, M.Q(ud), blk.downsample[1])
     else:
@@ -145,3 +148,151 @@ def test_plan_block_by_block(layers, width, shape):
         e = rel_l2(grads[name].cpu(), p_.grad)
         assert e < 4e-2, (name, e)
     print("worst per-block parameter-gradient error %.3e" % worst)
+
+
+def test_plan_first_blocks_at_the_benchmarked_batch():
+    """The same block-by-block check INSIDE the benchmarked plan (configs[1]: batch 256 of 256 x 128, ResNet-50 (3, 4, 6, 3)), restricted to
+    the stem and the first bottleneck of every layer -- the four blocks with a downsample branch, both strides, the moments scheme of layer1's
+    branch -- so that the CPU twin stays cheap.  At this batch the plan takes its own tile shapes, statistic-tile counts, split-K counts, the
+    Gram path at P = 524288 and the persistent streaming kernel for conv3 / the masked conv1 gradients; the batch-8 case above takes none of
+    them.  The plan's own block input and the plan's own incoming gradient (read block by block through dali_debug_resnet_backward_block) go
+    through the rounding-matched twin of ONE block: output, data gradient and every parameter gradient, same bounds as above."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ctypes
+    from daliid_amd import Encoders, _lib
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    layers, width, n, H, W = (3, 4, 6, 3), 64, 256, 256, 128
+    torch.manual_seed(4)
+    ref = OracleNet(layers=layers, width=width)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                m.weight.copy_(0.5 + torch.rand(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+    net = Encoders.ResNet50ReID(layers=layers, width=width)
+    net.load_state_dict(ref.state_dict())
+    ref.train(); net.train()
+    x = torch.randn(n, 3, H, W, generator=g)
+    d_emb = torch.randn(n, width * 32, generator=g).cuda()
+    net._run_forward(x.cuda(), training=True)
+    blocks = [b for l in (ref.layer1, ref.layer2, ref.layer3, ref.layer4) for b in l]
+    names = ["layer%d.%d" % (li + 1, bi) for li, l in enumerate((ref.layer1, ref.layer2, ref.layer3, ref.layer4)) for bi in range(len(l))]
+    first = [0, 3, 7, 13]                                          # first bottleneck of layer1 .. layer4
+    hw = [(H // 4, W // 4)]
+    for li, l in enumerate(layers):
+        for bi in range(l):
+            h, w = hw[-1]
+            if bi == 0 and li in (1, 2):
+                h, w = h // 2, w // 2
+            hw.append((h, w))
+
+    def nchw(name, c, h, w):
+        return net.debug_tensor(name, bf16, (n, h, w, c)).float().cpu().permute(0, 3, 1, 2).contiguous()
+    L = _lib.lib()
+    L.dali_debug_resnet_backward_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    plan = net._last_plan.h
+    # backward block by block; keep the gradient ENTERING each first block (= grad_cur after the block behind it) and the one it hands on
+    dy_in, dx_out, d_raw = {}, {}, {}
+    for bi in range(len(blocks) - 1, -1, -1):
+        if bi in first:
+            c, (h, w) = blocks[bi].conv3.out_channels, hw[bi + 1]
+            if bi == len(blocks) - 1:
+                raise AssertionError("the last block is never a first block of ResNet-50")
+            dy_in[bi] = nchw("grad_cur", c, h, w)
+        _lib.check(L.dali_debug_resnet_backward_block(plan, _lib.stream_ptr(), _lib.ptr(d_emb), bi), "dali_debug_resnet_backward_block")
+        if bi in first:
+            dx_out[bi] = nchw("grad_cur", blocks[bi].conv1.in_channels, *hw[bi])
+            wdt = blocks[bi].conv1.out_channels
+            d_raw[bi] = (nchw("block%d.d_raw1" % bi, wdt, *hw[bi]),)
+    _lib.check(L.dali_debug_resnet_backward_block(plan, _lib.stream_ptr(), _lib.ptr(d_emb), -1), "dali_debug_resnet_backward_block")
+    torch.cuda.synchronize()
+    grads = {k: v.cpu() for k, v in net._grad_views.items()}
+    worst, report, bad = 0.0, [], []
+    for bi in first:
+        blk = blocks[bi]
+        cin, cout = blk.conv1.in_channels, blk.conv3.out_channels
+        xin = (nchw("pool0", width, *hw[0]) if bi == 0 else nchw("block%d.y" % (bi - 1), cin, *hw[bi])).requires_grad_(True)
+        y_plan = nchw("block%d.y" % bi, cout, *hw[bi + 1])
+        for p_ in blk.parameters():
+            p_.grad = None
+        keep = {}
+        yo = block_forward_matched_first(blk, xin, bi == 0, keep)
+        e = rel_l2(y_plan, yo.detach())
+        report.append("%s forward %.2e" % (names[bi], e))
+        if not e < 6e-3: bad.append(("forward", names[bi], e))
+        yo.backward(dy_in[bi])                                     # the plan's masked gradient dz of this block's output
+        want_dx = xin.grad.to(bf16).float()
+        if bi > 0:
+            want_dx = want_dx * (xin.detach() > 0)                 # the plan hands on dz of the PREVIOUS block's output
+        e = rel_l2(dx_out[bi], want_dx)
+        report.append("%s data gradient %.2e" % (names[bi], e))
+        if not e < 4e-2: bad.append(("data gradient", names[bi], e))
+        report.append("%s d_raw1 (the stored gradient of conv1's raw output) vs the twin's %.2e" % (names[bi], rel_l2(d_raw[bi][0], keep["conv1"][1].grad)))
+        for pname, p_ in blk.named_parameters():
+            got = grads[names[bi] + "." + pname]
+            e = rel_l2(got, p_.grad)
+            scale_free = float((got - p_.grad).abs().max() / p_.grad.abs().max().clamp(min=1e-30))
+            worst = max(worst, min(e, scale_free))
+            report.append("%s %s rel-L2 %.2e max-abs/max %.2e" % (names[bi], pname, e, scale_free))
+            if not (e < 4e-2 or scale_free < 2e-2):
+                # Found at batch 256 on layer1.0's conv1.weight (plan vs twin 5.7e-2).  Traced: the plan's stored d_raw1 agrees with the twin's to 5e-3
+                # element by element; the weight-gradient kernel reproduces its sum from that stored operand to 1e-5 (and is accurate to 7e-8 under
+                # cancellation, scripts/wgrad_cancel_probe.py); shifting the twin's BatchNorm gradient sums to the plan's values, or giving the twin
+                # the bf16 weight images of the moments scheme, changes nothing.  What remains is the quantity itself: against the UN-ROUNDED fp32
+                # block (plain autograd on the same input and incoming gradient) the twin -- a CPU program -- is 8.9e-2 off and the plan 1.07e-1:
+                # two stacked BatchNorm backwards leave conv1's weight gradient as a small residual of sums over 524288 pixels, and bf16 storage of
+                # the gradients above it moves it by ~10 % in ANY implementation.  Bound such a parameter the way the end-to-end tests do: the plan
+                # must be no further from the twin than the twin is from fp32, and at most 1.5 x as far from fp32 as the twin.
+                saved = {n_: q_.grad.clone() for n_, q_ in blk.named_parameters()}
+                for q_ in blk.parameters():
+                    q_.grad = None
+                x3 = xin.detach().clone().requires_grad_(True)
+                bnf = lambda t_, m_: F.batch_norm(t_, None, None, m_.weight, m_.bias, True, 0.0, 1e-5)
+                a_ = F.relu(bnf(F.conv2d(x3, blk.conv1.weight), blk.bn1))
+                a_ = F.relu(bnf(F.conv2d(a_, blk.conv2.weight, stride=blk.conv2.stride, padding=1), blk.bn2))
+                o_ = bnf(F.conv2d(a_, blk.conv3.weight), blk.bn3) + bnf(F.conv2d(x3, blk.downsample[0].weight, stride=blk.downsample[0].stride), blk.downsample[1])
+                F.relu(o_).backward(dy_in[bi])
+                e_plan32, e_twin32 = rel_l2(got, p_.grad), rel_l2(saved[pname], p_.grad)
+                report.append("%s %s against the un-rounded fp32 block: plan %.2e, twin %.2e" % (names[bi], pname, e_plan32, e_twin32))
+                for n_, q_ in blk.named_parameters():
+                    q_.grad = saved[n_]
+                del x3, a_, o_
+                if e <= e_twin32 and e_plan32 <= 1.5 * e_twin32:
+                    continue
+                bad.append((names[bi], pname, e, scale_free))
+        del xin, yo, y_plan
+    # stem: oracle stem forward / backward from the image with the plan's d(pool0)
+    pool0 = nchw("pool0", width, *hw[0])
+    for p_ in list(ref.conv1.parameters()) + list(ref.bn1.parameters()):
+        p_.grad = None
+    u = M._conv(M.Q(x), ref.conv1)
+    p0 = M.Q(F.max_pool2d(M._bn_train(u, M.Q(u), ref.bn1), 3, 2, 1))
+    assert rel_l2(pool0, p0.detach()) < 3e-3
+    p0.backward(dx_out[0])
+    for name, p_ in (("conv1.weight", ref.conv1.weight), ("bn1.weight", ref.bn1.weight)):
+        e = rel_l2(grads[name], p_.grad)
+        assert e < 4e-2, (name, e)
+    print("\n".join(report))
+    print("batch 256: worst first-block parameter-gradient error %.3e" % worst)
+    assert not bad, bad
+
+
+def block_forward_matched_first(blk, x, first_of_net, keep=None):
+    """block_forward_matched with the downsample branch's rounding point of the net's first block (its BatchNorm backward runs through the moments
+    of the block input: no d_rawd tensor, resnet_plan.hip lin_ds / oracle ds_through_moments).  keep (dict): receives conv1's input and raw output (whose gradient the test reads)."""
+    u1 = M._conv(x, blk.conv1); a1 = M.Q(F.relu(M._bn_train(u1, M.Q(u1), blk.bn1)))
+    u2 = M._conv(a1, blk.conv2); a2 = M.Q(F.relu(M._bn_train(u2, M.Q(u2), blk.bn2)))
+    if not M.stores_raw3(blk):
+        out = M._Conv3Bn3Moments.apply(a2, blk.conv3.weight, blk.bn3.weight, blk.bn3.bias, 1e-5)
+        u3 = None
+    else:
+        u3 = M._conv(a2, blk.conv3)
+        out = M._bn_train(u3, M.Q(u3), blk.bn3)
+    ud = M._conv(x, blk.downsample[0])
+    idn = M._bn_train(ud, (M.QF if M.ds_through_moments(blk, first_of_net) else M.Q)(ud), blk.downsample[1])
+    if keep is not None:
+        u1.retain_grad()
+        keep.update({"conv1": (x, u1)})
+    return M.Q(F.relu(out + idn))
