@@ -2744,11 +2744,14 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
 #define DALI_F1_LAUNCH(RES, OM, BITS)                                                                                                                     \
     do {                                                                                                                                                  \
         DALI_ONCE_PER_DEVICE({                                                                                                                            \
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<2, 2, RES, OM, BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(2, 2))); \
-            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<3, 1, RES, OM, BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(3, 1))); \
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<3, 2, true, RES, OM, BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(3, 2, true, 128))); \
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<3, 1, true, RES, OM, BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(3, 1, true, 256))); \
+            DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<3, 1, false, RES, OM, BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(3, 1, false, 0))); \
         });                                                                                                                                               \
-        if (a.g.Ck <= 128) hipLaunchKernelGGL((fused1x1_persist_kernel<2, 2, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(2, 2), st, args, tiles_m, tiles_n); \
-        else hipLaunchKernelGGL((fused1x1_persist_kernel<3, 1, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(3, 1), st, args, tiles_m, tiles_n); \
+        const int kk = a.g.Ck;                                                                                                                            \
+        if (kk <= 128) hipLaunchKernelGGL((fused1x1_persist_kernel<3, 2, true, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(3, 2, true, kk), st, args, tiles_m, tiles_n); \
+        else if (kk <= 256) hipLaunchKernelGGL((fused1x1_persist_kernel<3, 1, true, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(3, 1, true, kk), st, args, tiles_m, tiles_n); \
+        else hipLaunchKernelGGL((fused1x1_persist_kernel<3, 1, false, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(3, 1, false, kk), st, args, tiles_m, tiles_n); \
     } while (0)
                 const bool f_res = a.Res != nullptr, f_om = a.out_mask != nullptr, f_bits = a.bits_out != nullptr;
                 if (f_res && !f_om && f_bits) DALI_F1_LAUNCH(true, false, true);          // conv3 forward of the train step

@@ -89,20 +89,25 @@ constexpr int F1_M_BYTES = F1_TN * F1_TM / 8;                         // mask by
 constexpr int F1_C_BYTES = 3 * F1_TM * 4;                             // scale, shift (+ bias), residual scale of the workgroup's channel tile
 // NS ring stages, RB residual buffers: <2, 2> for K <= 128 (the main loop is too short to hide a residual fetch: it is requested a tile ahead),
 // <3, 1> for K >= 256
-constexpr int f1_lds_bytes(int NS, int RB) { return NS * F1_STAGE_ELEMS * 2 + RB * F1_R_BYTES + RB * F1_M_BYTES + F1_C_BYTES; }
+// ARES: the workgroup's 128 weight rows (all of K) stay in LDS for the whole launch -- every workgroup keeps ONE channel tile -- and the ring
+// carries the pixel rows only: half the DMA pieces per k-step (the ring producers' issue rate, not the MFMA, set the main beats' length)
+constexpr int f1_lds_bytes(int NS, int RB, bool ARES, int K) {
+    return (ARES ? F1_TM * K * 2 + NS * F1_TN * 64 * 2 : NS * F1_STAGE_ELEMS * 2) + RB * F1_R_BYTES + RB * F1_M_BYTES + F1_C_BYTES;
+}
 
 // HAS_RES / HAS_OM / HAS_BITS: residual, output mask, mask bits of the result -- compile-time, so that the two output-stage beats are straight-line
 // code (with run-time flags every LDS read sat behind a branch and waited for its own latency: 1.4 + 0.7 us per tile)
-template <int F1_NS, int F1_RB, bool HAS_RES, bool HAS_OM, bool HAS_BITS>
+template <int F1_NS, int F1_RB, bool ARES, bool HAS_RES, bool HAS_OM, bool HAS_BITS>
 __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
-    constexpr int F1_RING_BYTES = F1_NS * F1_STAGE_ELEMS * 2;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    char* const rbuf = reinterpret_cast<char*>(smem) + F1_RING_BYTES;
+    const int K = a.g.Ck, KT = K >> 6, P = a.P, Cm = a.Cm;
+    constexpr int STAGE = ARES ? F1_TN * 64 : F1_STAGE_ELEMS;             // elements of a ring stage
+    uint16_t* const ring = smem + (ARES ? F1_TM * K : 0);                 // (ARES: the resident weight image [K / 64][128 rows][64] sits in front)
+    char* const rbuf = reinterpret_cast<char*>(ring + F1_NS * STAGE);
     char* const mbuf = rbuf + F1_RB * F1_R_BYTES;
     float* const cbuf = reinterpret_cast<float*>(mbuf + F1_RB * F1_M_BYTES);         // [3][128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = a.g.Ck, KT = K >> 6, P = a.P, Cm = a.Cm;
     // ---- this workgroup's tiles ----
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
     const int n0 = (int)((long long)xcd * tiles_n / 8), n1 = (int)((long long)(xcd + 1) * tiles_n / 8);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
         const int r_in = lane >> 3;
         const int kc = (lane & 7) ^ (((pw & 1) << 2) | (r_in >> 1));
         constexpr int NPC = F1_TM / 8 / F1_NP;                        // pieces per producer, operand and k-step: 4
-        constexpr int PK = 2 * NPC;                                   // DMA pieces per producer and k-step: 8
+        constexpr int PK = ARES ? NPC : 2 * NPC;                      // DMA pieces per producer and k-step: 4 (pixels only) or 8
         int issued = 0, it = 0, ik = 0, st_issue = 0;
         uint32_t a_off[NPC], b_off[NPC];
         auto set_tile = [&](int t) {
@@ -141,14 +146,22 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
             }
         };
         set_tile(0);
+        if constexpr (ARES) {                                         // the weight rows of this workgroup's channel tile, once (older than every ring piece:
+            for (int k = 0; k < KT; ++k)                              //  the first counted wait below covers them)
+#pragma unroll
+                for (int i = 0; i < NPC; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(smem + k * (F1_TM * 64) + (pw + F1_NP * i) * 512), 16, a_off[i] + (uint32_t)k * 128u, 0, 0, 0);
+        }
         auto issue_one = [&]() {
-            uint16_t* sa = smem + st_issue * F1_STAGE_ELEMS;
-            uint16_t* sb = sa + F1_TM * 64;
+            uint16_t* sa = ring + st_issue * STAGE;
+            uint16_t* sb = ARES ? sa : sa + F1_TM * 64;
             st_issue = st_issue == F1_NS - 1 ? 0 : st_issue + 1;
             const uint32_t kb = (uint32_t)ik * 128u;
+            if constexpr (!ARES) {
 #pragma unroll
-            for (int i = 0; i < NPC; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (pw + F1_NP * i) * 512), 16, a_off[i] + kb, 0, 0, 0);
+                for (int i = 0; i < NPC; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (pw + F1_NP * i) * 512), 16, a_off[i] + kb, 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
                 const uint32_t off = b_off[i] == DMA_OOB ? DMA_OOB : b_off[i] + kb;
@@ -273,9 +286,9 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
             for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < KT; ++k) {
             const unsigned long long s0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
-            const uint16_t* sa = smem + st_cur * F1_STAGE_ELEMS;
+            const uint16_t* sb = ring + st_cur * STAGE + (ARES ? 0 : F1_TM * 64);
+            const uint16_t* sa = ARES ? smem + k * (F1_TM * 64) : ring + st_cur * STAGE;
             st_cur = st_cur == F1_NS - 1 ? 0 : st_cur + 1;
-            const uint16_t* sb = sa + F1_TM * 64;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int fo = frag_off ^ (h << 5);
@@ -300,44 +313,37 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
         {
             // all LDS reads first (residual slots, coefficients), then the arithmetic, then all writes: the in-place writes may alias the reads as
             // far as the compiler can tell, so interleaved they serialised the tile's eight LDS round trips (1.2 us per tile)
-            uint2* slot[4][2];
-            uint2 rv[4][2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            // (slot addresses are recomputed, not kept in an array of pointers: that array went to scratch memory in some instantiations)
+            auto slot_of = [&](int i, int j) -> uint2* {
                 const int pix = wn * 32 + j * 16 + (lane & 15);
-                char* row = rb + pix * 256 + ((lane >> 4) & 1) * 8;
+                const int chunk = wm * 8 + i * 2 + (lane >> 5);
+                return reinterpret_cast<uint2*>(rb + pix * 256 + ((lane >> 4) & 1) * 8 + ((chunk ^ (pix & 15)) << 4));
+            };
+            const float lo = relu ? 0.f : -__builtin_huge_valf();         // ReLU without a branch: max(v, lo)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                                 // one 16-pixel column block at a time: its four residual slots are read
+                uint2 rv[4];                                              // together (one LDS round trip), then overwritten in place
+                if (has_res) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rv[i] = *slot_of(i, j);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int chunk = wm * 8 + i * 2 + (lane >> 5);
-                    slot[i][j] = reinterpret_cast<uint2*>(row + ((chunk ^ (pix & 15)) << 4));
-                    if (has_res) rv[i][j] = *slot[i][j];
-                }
-            }
-            const float lo = relu ? 0.f : -__builtin_huge_valf();         // ReLU without a branch: max(v, lo)
-            uint2 ov[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = wm * 64 + i * 16 + (lane >> 4) * 4;         // (the coefficients of one 16-channel block at a time: all twelve vectors at once spilled)
-                const float4 s4 = *reinterpret_cast<const float4*>(cbuf + c), h4 = *reinterpret_cast<const float4*>(cbuf + F1_TM + c);
-                float4 r4 = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (has_res) r4 = *reinterpret_cast<const float4*>(cbuf + 2 * F1_TM + c);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                    const int c = wm * 64 + i * 16 + (lane >> 4) * 4;
+                    const float4 s4 = *reinterpret_cast<const float4*>(cbuf + c), h4 = *reinterpret_cast<const float4*>(cbuf + F1_TM + c);
+                    float4 r4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (has_res) r4 = *reinterpret_cast<const float4*>(cbuf + 2 * F1_TM + c);
                     // explicit fused multiply-adds (the library is built with -ffp-contract=off): the output stage is VALU-issue bound, ~5 -> ~3.5
                     // instructions per element; one rounding fewer than the tile-per-workgroup kernels' mul + add, same value on exact data
                     float v0 = __builtin_fmaf(acc[i][j][0], s4.x, h4.x), v1 = __builtin_fmaf(acc[i][j][1], s4.y, h4.y);
                     float v2 = __builtin_fmaf(acc[i][j][2], s4.z, h4.z), v3 = __builtin_fmaf(acc[i][j][3], s4.w, h4.w);
                     if (has_res) {
-                        v0 = __builtin_fmaf(r4.x, bf16_bits_to_f32(rv[i][j].x & 0xffffu), v0); v1 = __builtin_fmaf(r4.y, bf16_bits_to_f32(rv[i][j].x >> 16), v1);
-                        v2 = __builtin_fmaf(r4.z, bf16_bits_to_f32(rv[i][j].y & 0xffffu), v2); v3 = __builtin_fmaf(r4.w, bf16_bits_to_f32(rv[i][j].y >> 16), v3);
+                        v0 = __builtin_fmaf(r4.x, bf16_bits_to_f32(rv[i].x & 0xffffu), v0); v1 = __builtin_fmaf(r4.y, bf16_bits_to_f32(rv[i].x >> 16), v1);
+                        v2 = __builtin_fmaf(r4.z, bf16_bits_to_f32(rv[i].y & 0xffffu), v2); v3 = __builtin_fmaf(r4.w, bf16_bits_to_f32(rv[i].y >> 16), v3);
                     }
-                    ov[i][j] = make_uint2(pack_bf16x2(fmaxf(v0, lo), fmaxf(v1, lo)), pack_bf16x2(fmaxf(v2, lo), fmaxf(v3, lo)));
+                    *slot_of(i, j) = make_uint2(pack_bf16x2(fmaxf(v0, lo), fmaxf(v1, lo)), pack_bf16x2(fmaxf(v2, lo), fmaxf(v3, lo)));
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *slot[i][j] = ov[i][j];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long e0e = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -347,24 +353,26 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
         const bool interior = (tn + 1) * F1_TN <= P;
         const char* mb = mbuf + (F1_RB == 2 ? (t & 1) : 0) * F1_M_BYTES;
         if (interior) {
-            uint4 v[4];
-            unsigned mk[4];
-#pragma unroll
-            for (int itr = 0; itr < 4; ++itr) {                        // all LDS reads first: one round trip for the four chunks
+            // all four LDS reads first (one round trip), then gate / bits / stores.  (Four named values: as an array indexed in two loops the
+            // compiler kept a copy of it in scratch memory -- dead stores, but vector-memory operations of the consumers.)
+            auto ld = [&](int itr) { const int s = itr * (F1_NC * 64) + tid, pix = s >> 4, chunk = s & 15;
+                                     return *reinterpret_cast<const uint4*>(rb + pix * 256 + ((chunk ^ (pix & 15)) << 4)); };
+            auto ldm = [&](int itr) -> unsigned { const int s = itr * (F1_NC * 64) + tid, pix = s >> 4, chunk = s & 15;
+                                                   return has_om ? *reinterpret_cast<const uint8_t*>(mb + pix * 16 + chunk) : 0u; };
+            auto put = [&](int itr, uint4 v, unsigned m) {
                 const int s = itr * (F1_NC * 64) + tid, pix = s >> 4, chunk = s & 15;
-                v[itr] = *reinterpret_cast<const uint4*>(rb + pix * 256 + ((chunk ^ (pix & 15)) << 4));
-                if (has_om) mk[itr] = *reinterpret_cast<const uint8_t*>(mb + pix * 16 + chunk);
-            }
-#pragma unroll
-            for (int itr = 0; itr < 4; ++itr) {
-                const int s = itr * (F1_NC * 64) + tid, pix = s >> 4, chunk = s & 15;
-                if (has_om) {
-                    const unsigned m = mk[itr];
-                    v[itr].x = gate_bf16x2(v[itr].x, m); v[itr].y = gate_bf16x2(v[itr].y, m >> 2); v[itr].z = gate_bf16x2(v[itr].z, m >> 4); v[itr].w = gate_bf16x2(v[itr].w, m >> 6);
-                }
+                if (has_om) { v.x = gate_bf16x2(v.x, m); v.y = gate_bf16x2(v.y, m >> 2); v.z = gate_bf16x2(v.z, m >> 4); v.w = gate_bf16x2(v.w, m >> 6); }
                 const size_t e = ((size_t)(tn * F1_TN + pix) * Cm + tm * F1_TM + chunk * 8);
-                *reinterpret_cast<uint4*>(a.O + e) = v[itr];
-                if (has_bits) a.bits_out[e >> 3] = (uint8_t)(f1_pos_bits(v[itr].x) | (f1_pos_bits(v[itr].y) << 2) | (f1_pos_bits(v[itr].z) << 4) | (f1_pos_bits(v[itr].w) << 6));
+                *reinterpret_cast<uint4*>(a.O + e) = v;
+                if (has_bits) a.bits_out[e >> 3] = (uint8_t)(f1_pos_bits(v.x) | (f1_pos_bits(v.y) << 2) | (f1_pos_bits(v.z) << 4) | (f1_pos_bits(v.w) << 6));
+            };
+            if constexpr (has_res && has_om) {                         // (the masked-gradient instantiation sits at the 128-register cap: two round trips of two)
+                { const uint4 v0 = ld(0), v1 = ld(1); const unsigned k0 = ldm(0), k1 = ldm(1); put(0, v0, k0); put(1, v1, k1); }
+                { const uint4 v2 = ld(2), v3 = ld(3); const unsigned k2 = ldm(2), k3 = ldm(3); put(2, v2, k2); put(3, v3, k3); }
+            } else {
+            const uint4 v0 = ld(0), v1 = ld(1), v2 = ld(2), v3 = ld(3);
+            const unsigned k0 = ldm(0), k1 = ldm(1), k2 = ldm(2), k3 = ldm(3);
+            put(0, v0, k0); put(1, v1, k1); put(2, v2, k2); put(3, v3, k3);
             }
         } else {
 #pragma unroll
