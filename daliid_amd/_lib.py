@@ -49,6 +49,7 @@ _SIGNATURES = {
     "dali_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_int],
     "dali_conv1x1_fused": [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p],
     "dali_conv1x1_cat": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int],
+    "dali_conv1x1_cat_act": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int],
     "dali_bnlin_fwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 7,
     "dali_bnlin_bwd": [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 11,
     "dali_bn_finalize": [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -2662,6 +2662,29 @@ int launch_igemm_conv(hipStream_t st, const IGemmArgs& a) {
     return launch_igemm_conv_one(st, args);
 }
 
+// CUs of the current device rounded down to a multiple of 8 (the persistent streaming kernel's grid: one workgroup per CU, whole XCD groups)
+static int f1_cu_count() {
+    static int n_cus = 0;
+    if (!n_cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { set_error("conv: device query failed"); return -1; }
+        n_cus = v > 8 ? v & ~7 : 8;
+    }
+    return n_cus;
+}
+// does launch_igemm_conv take [X | X2] (c1 + c2 = K channels, plain rows) with the scale / shift / ReLU output stage at this size?  (dali_conv1x1_cat_act;
+// the net plan asks before it folds a downsample branch into conv3)
+bool conv_cat_act_supported(int Cm, int c1, int c2, int P, int parts) {
+    const int K = parts * (c1 + c2);
+    if (parts != 1 && parts != 2) return false;
+    if ((c1 & 63) || (c2 & 63) || (Cm % 128) || (long long)P * Cm * 2 >= 0x7ff00000ll || (long long)P * K * 2 >= 0x7ff00000ll) return false;
+    if (K <= DALI_ENV_INT("DALI_CONV_PERSIST_KMAX", 256) && DALI_ENV_INT("DALI_CONV_PERSIST", 1) != 0) {
+        const int n_cus = f1_cu_count(), tiles_m = Cm / 128, tiles_n = (P + 127) / 128;
+        return n_cus > 0 && (long long)tiles_m * tiles_n >= 2ll * n_cus && (n_cus / 8) % tiles_m == 0;
+    }
+    return parts == 1 && K >= 1024 && Cm >= 512 && P >= 16384 && conv_k64_mode() == 2 && conv_cfg_override() < 0;
+}
+
 static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     const bool in_bn = a.in_scale != nullptr;
     const bool narrow = a.Cm <= 64;
@@ -2695,14 +2718,26 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
     int k64 = (!in_bn && dma_ok && !narrow && a.g.Ck % 64 == 0) ? conv_k64_mode() : 0;
     int narrow_k64 = (!in_bn && dma_ok && narrow && a.g.Ck % 64 == 0 && K >= 512) ? conv_k64_mode() : 0;   // layer1's 3x3 (Cin = 64: a pixel is one line)
     if (a.X2) {                                         // two operand tensors (IGemmArgs::X2): the SRC2 instantiations of the 128 x 128 / 64 x 256 LDS-DMA kernel
-        const bool fo = a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale;
-        if (in_bn || !dma_ok || a.stats || fo || lin || a.g.sub || a.g.R != 1 || a.g.S != 1 || a.g.stride != 1 || a.g.pad != 0 || a.Ck1 <= 0 || a.Ck1 >= a.g.Ck ||
-            (a.Ck1 & 31) || ((a.g.Ck - a.Ck1) & 31) || (a.Cm & 7)) {
+        // a fused output stage beside X2: shift (+ scale) and ReLU only (the inference forward's conv3 + downsample branch as one GEMM), on the two
+        // kernels that have that instantiation: the persistent streaming kernel (K <= 256) and the 256 x 256 k-tile-64 kernel
+        const bool fo_simple = !a.bits_out && !a.out_mask && !a.res_scale && !a.Res && (a.out_scale || a.out_shift || a.out_relu);
+        const bool fo = (a.out_scale || a.out_shift || a.out_relu || a.bits_out || a.out_mask || a.res_scale) && !fo_simple;
+        const int xr = a.x_rep > 1 ? a.x_rep : 1;
+        if (xr > 1 && !(fo_simple && a.g.Ck % xr == 0 && conv_cat_act_supported(a.Cm, a.Ck1, a.g.Ck / xr - a.Ck1, a.P, xr) && a.g.Ck <= DALI_ENV_INT("DALI_CONV_PERSIST_KMAX", 256))) {
+            set_error("conv: split weight images (x_rep = %d) are served by the persistent streaming kernel only (K <= 256, >= 2 tiles per CU)", xr);
+            return DALI_ERR_INVALID;
+        }
+        if (fo_simple && ((a.Ck1 & 63) || ((a.g.Ck / xr - a.Ck1) & 63) || (a.Cm % 128))) {
+            set_error("conv: two operand tensors with a fused output stage need channel counts that are multiples of 64 and Cm %% 128 == 0");
+            return DALI_ERR_INVALID;
+        }
+        if (in_bn || !dma_ok || a.stats || fo || lin || a.g.sub || a.g.R != 1 || a.g.S != 1 || a.g.stride != 1 || a.g.pad != 0 || a.Ck1 <= 0 || a.Ck1 >= a.g.Ck / xr ||
+            (a.Ck1 & 31) || ((a.g.Ck / xr - a.Ck1) & 31) || (a.Cm & 7)) {
             set_error("conv: a second operand tensor needs a plain 1x1 / stride 1 problem with both channel counts multiples of 32");
             return DALI_ERR_INVALID;
         }
         narrow_k64 = 0;
-        if ((a.Ck1 & 63) || ((a.g.Ck - a.Ck1) & 63)) k64 = 0;
+        if ((a.Ck1 & 63) || ((a.g.Ck / xr - a.Ck1) & 63)) k64 = 0;
         if (!(k64 && (cfg == CONV_256x256 || cfg == CONV_128x256)) && !narrow) { cfg = CONV_128; k64 = 0; }
     }
     if ((k64 == 2 || k64 == 6) && cfg != CONV_256x320 && !((K >= 1024 && (cfg == CONV_256x256 || cfg == CONV_128x256)) || (K >= 768 && cfg == CONV_256x256))) k64 = 0;
@@ -2727,17 +2762,12 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         // 1x1 conv3 forwards and the masked conv1 data gradients, Cm >= 256 and K <= 512)
         // short-K 1x1 with a residual / mask stream: the persistent streaming kernel (fused1x1.h).  K <= 256: at K = 512 (layer4) its four ring
         // producers cannot issue the 32 DMA pieces of a k-step as fast as the consumers multiply it (141 against 125 us; the block is capped at 16 waves)
-        if (DALI_ENV_INT("DALI_CONV_PERSIST", 1) != 0 && a.g.R == 1 && a.g.S == 1 && a.g.stride == 1 && a.g.pad == 0 && !a.g.sub && !a.X2 && !a.res_mask &&
+        if (DALI_ENV_INT("DALI_CONV_PERSIST", 1) != 0 && a.g.R == 1 && a.g.S == 1 && a.g.stride == 1 && a.g.pad == 0 && !a.g.sub && !a.res_mask &&
             (a.Cm % F1_TM) == 0 && (a.g.Ck & 63) == 0 && a.g.Ck <= DALI_ENV_INT("DALI_CONV_PERSIST_KMAX", 256) && a.g.pix_pitch == a.g.Ck && a.g.row_pitch == a.g.Win * a.g.Ck &&
             a.g.img_pitch == (long long)a.g.Hin * a.g.Win * a.g.Ck && a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout &&
-            (long long)a.P * a.Cm * 2 < 0x7ff00000ll && (a.Res || a.out_mask || a.bits_out)) {
-            static int n_cus = 0;
-            if (!n_cus) {
-                int dev = 0, v = 0;
-                DALI_HIP(hipGetDevice(&dev));
-                DALI_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-                n_cus = v > 8 ? v & ~7 : 8;
-            }
+            (long long)a.P * a.Cm * 2 < 0x7ff00000ll && (a.Res || a.out_mask || a.bits_out || a.X2)) {
+            const int n_cus = f1_cu_count();
+            if (n_cus <= 0) return DALI_ERR_HIP;
             const int tiles_m = a.Cm / F1_TM, tiles_n = (a.P + F1_TN - 1) / F1_TN;
             if ((long long)tiles_m * tiles_n >= 2ll * n_cus && (n_cus / 8) % tiles_m == 0) {     // (every workgroup keeps one channel tile)
                 const dim3 f1_block((F1_NC + F1_NP + F1_NR) * 64);
@@ -2754,7 +2784,14 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         else hipLaunchKernelGGL((fused1x1_persist_kernel<3, 1, false, RES, OM, BITS>), dim3(n_cus), f1_block, f1_lds_bytes(3, 1, false, kk), st, args, tiles_m, tiles_n); \
     } while (0)
                 const bool f_res = a.Res != nullptr, f_om = a.out_mask != nullptr, f_bits = a.bits_out != nullptr;
-                if (f_res && !f_om && f_bits) DALI_F1_LAUNCH(true, false, true);          // conv3 forward of the train step
+                if (a.X2) {                                                               // [X | X2] against one weight image, shift + ReLU (inference)
+                    DALI_ONCE_PER_DEVICE({
+                        DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<3, 2, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(3, 2, true, 128)));
+                        DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused1x1_persist_kernel<3, 1, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, f1_lds_bytes(3, 1, true, 256)));
+                    });
+                    if (a.g.Ck <= 128) hipLaunchKernelGGL((fused1x1_persist_kernel<3, 2, true, false, false, false, true>), dim3(n_cus), f1_block, f1_lds_bytes(3, 2, true, a.g.Ck), st, args, tiles_m, tiles_n);
+                    else hipLaunchKernelGGL((fused1x1_persist_kernel<3, 1, true, false, false, false, true>), dim3(n_cus), f1_block, f1_lds_bytes(3, 1, true, a.g.Ck), st, args, tiles_m, tiles_n);
+                } else if (f_res && !f_om && f_bits) DALI_F1_LAUNCH(true, false, true);          // conv3 forward of the train step
                 else if (f_res && !f_om && !f_bits) DALI_F1_LAUNCH(true, false, false);   // conv3 forward, inference
                 else if (f_res && f_om && !f_bits) DALI_F1_LAUNCH(true, true, false);     // conv1 data gradient + identity gradient, masked
                 else if (!f_res && f_om && !f_bits) DALI_F1_LAUNCH(false, true, false);   // masked data gradient without a residual
@@ -2769,7 +2806,7 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
         const bool halo_ok = narrow_k64 == 2 && a.Cm == 64 && a.g.Ck == 64 && a.g.R == 3 && a.g.S == 3 && a.g.stride == 1 && a.g.pad == 1 && !a.g.sub &&
                              (a.g.Wout == 16 || a.g.Wout == 32) && args.g.lhw >= 8 && a.g.Hin == a.g.Hout && a.g.Win == a.g.Wout && a.g.pix_pitch == 64 &&
                              a.g.row_pitch == a.g.Win * 64 && a.g.img_pitch == (long long)a.g.Hin * a.g.Win * 64 && a.P % 256 == 0;
-        const bool lean = !a.Res && !a.out_mask && !a.bits_out && !a.res_mask && !a.res_scale;      // scale / shift / bias / ReLU only: the EPI = 5 instantiations
+        const bool lean = !a.Res && !a.out_mask && !a.bits_out && !a.res_mask && !a.res_scale && !a.X2;      // scale / shift / bias / ReLU only: the EPI = 5 instantiations
         if (halo_ok && lean) {
             const int lds = (3 * 64 * 64 + HALO64_PX * 64) * 2;
             DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_halo64_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
@@ -2784,6 +2821,15 @@ static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a) {
             const int lds = (128 + 256) * 64 * 2 * 3;
             DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
             hipLaunchKernelGGL((igemm_conv_k64s_kernel<2, 4, 8, 3, 4, 4, 5>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), lds, st, args, tiles_m, tiles_n);
+        } else if (a.X2) {
+            // two operand tensors + fused output: the 256 x 256 k-tile-64 kernel only (the dispatch above sends the short-K case to fused1x1)
+            if (!(k64 && cfg == CONV_256x256)) {
+                set_error("conv: two operand tensors with a fused output stage need K <= 256 or a 256 x 256 k-tile-64 problem (K >= 1024, Cm >= 512, >= 16384 pixels)");
+                return DALI_ERR_INVALID;
+            }
+            const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
+            DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 256) * 64 * 2 * 2)));
+            hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3, true>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
         } else if (k64 && cfg == CONV_256x256) {
             const int tiles_m = (a.Cm + 255) / 256, tiles_n = (a.P + 255) / 256;
             hipLaunchKernelGGL((igemm_conv_k64_kernel<4, 4, 2, 4, 4, 3>), dim3(xcd_tile_grid(tiles_m, tiles_n)), dim3(1024), (256 + 256) * 64 * 2 * 2, st, args, tiles_m, tiles_n);
@@ -3251,6 +3297,20 @@ extern "C" int dali_conv1x1_cat(dali_ctx* ctx, void* stream, const uint16_t* x1,
     a.W = w; a.X = x1; a.X2 = x2; a.Ck1 = c1; a.O = y; a.bias = bias;
     a.Cm = cout; a.P = pixels;
     fill_geom(a.g, 1, 1, pixels, c1 + c2, 1, pixels, 1, 1, 1, 0, 0);
+    return launch_igemm_conv((hipStream_t)stream, a);
+}
+
+// y [pixels][cout] = relu?( [x1 | x2] @ w^T * out_scale + out_shift ): the two-operand GEMM with the scale / shift / ReLU output stage
+extern "C" int dali_conv1x1_cat_act(dali_ctx* ctx, void* stream, const uint16_t* x1, int c1, const uint16_t* x2, int c2, const uint16_t* w, int weight_parts,
+                                    const float* out_scale, const float* out_shift, int out_relu, uint16_t* y, int pixels, int cout) {
+    DALI_REQUIRE(ctx && x1 && x2 && w && y && out_shift, "dali_conv1x1_cat_act: null argument");
+    DALI_REQUIRE(c1 > 0 && c2 > 0 && c1 % 64 == 0 && c2 % 64 == 0 && cout % 128 == 0 && pixels > 0, "dali_conv1x1_cat_act: c1 %% 64, c2 %% 64, cout %% 128 (c1=%d c2=%d cout=%d)", c1, c2, cout);
+    IGemmArgs a{};
+    DALI_REQUIRE(weight_parts == 1 || weight_parts == 2, "dali_conv1x1_cat_act: weight_parts must be 1 or 2");
+    a.W = w; a.X = x1; a.X2 = x2; a.Ck1 = c1; a.x_rep = weight_parts; a.O = y;
+    a.out_scale = out_scale; a.out_shift = out_shift; a.out_relu = out_relu;
+    a.Cm = cout; a.P = pixels;
+    fill_geom(a.g, 1, 1, pixels, weight_parts * (c1 + c2), 1, pixels, 1, 1, 1, 0, 0);
     return launch_igemm_conv((hipStream_t)stream, a);
 }
 

@@ -97,7 +97,9 @@ constexpr int f1_lds_bytes(int NS, int RB, bool ARES, int K) {
 
 // HAS_RES / HAS_OM / HAS_BITS: residual, output mask, mask bits of the result -- compile-time, so that the two output-stage beats are straight-line
 // code (with run-time flags every LDS read sat behind a branch and waited for its own latency: 1.4 + 0.7 us per tile)
-template <int F1_NS, int F1_RB, bool ARES, bool HAS_RES, bool HAS_OM, bool HAS_BITS>
+// SRC2: the K dimension is the channels of X followed by those of a second plain [P][channels] tensor X2 (IGemmArgs::X2 / Ck1, both multiples of
+// 64): conv3 and the downsample convolution of a bottleneck as ONE GEMM in the inference forward ([a2 | x] against [s3.W3 | sd.Wd])
+template <int F1_NS, int F1_RB, bool ARES, bool HAS_RES, bool HAS_OM, bool HAS_BITS, bool SRC2 = false>
 __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist_kernel(IGemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     const int K = a.g.Ck, KT = K >> 6, P = a.P, Cm = a.Cm;
@@ -125,7 +127,10 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
         // ---------------- ring producers: the operand k-steps, nothing else ----------------
         const int pw = wave - F1_NC;
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), 0, Cm * K * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)((long long)P * K * 2), 0x00020000);
+        const int rep = SRC2 && a.x_rep > 1 ? a.x_rep : 1;             // (SRC2) each tensor's channels appear rep times: [X x rep | X2 x rep]
+        const int Ck1 = SRC2 ? a.Ck1 : K, Ck2 = K / rep - Ck1;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.X), 0, (int)((long long)P * Ck1 * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SRC2 ? a.X2 : a.X), 0, (int)((long long)P * (SRC2 ? Ck2 : Ck1) * 2), 0x00020000);
         // a DMA piece = 8 rows x 128 bytes; LDS slot `lane` of piece q = row 8q + (lane >> 3), physical chunk lane & 7 = logical chunk ^ ((row >> 1) & 7)
         // (the k-tile-64 image of igemm_conv_k64_kernel); q = pw + F1_NP i has the parity of pw, so the logical chunk is the same for all of a lane's pieces
         const int r_in = lane >> 3;
@@ -142,7 +147,8 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
                 const int m = tm * F1_TM + 8 * (pw + F1_NP * i) + r_in;
                 a_off[i] = (uint32_t)(m * K + kc * 8) * 2u;
                 const int p = tn * F1_TN + 8 * (pw + F1_NP * i) + r_in;
-                b_off[i] = p < P ? (uint32_t)(p * K + kc * 8) * 2u : DMA_OOB;
+                if constexpr (SRC2) b_off[i] = p < P ? (uint32_t)p : DMA_OOB;       // the pixel itself: the row pitch differs between the two tensors
+                else b_off[i] = p < P ? (uint32_t)(p * K + kc * 8) * 2u : DMA_OOB;
             }
         };
         set_tile(0);
@@ -162,10 +168,22 @@ __global__ __launch_bounds__((F1_NC + F1_NP + F1_NR) * 64) void fused1x1_persist
                 for (int i = 0; i < NPC; ++i)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)(sa + (pw + F1_NP * i) * 512), 16, a_off[i] + kb, 0, 0, 0);
             }
+            if constexpr (SRC2) {                                     // this k-step lies in X (< Ck1) or in X2: wave-uniform
+                const int kc0 = ik * 64;
+                const bool second = kc0 >= rep * Ck1;
+                const int pitch = second ? Ck2 : Ck1, cbase = (second ? (kc0 - rep * Ck1) % Ck2 : kc0 % Ck1) + kc * 8;
 #pragma unroll
-            for (int i = 0; i < NPC; ++i) {
-                const uint32_t off = b_off[i] == DMA_OOB ? DMA_OOB : b_off[i] + kb;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (pw + F1_NP * i) * 512), 16, off, 0, 0, 0);
+                for (int i = 0; i < NPC; ++i) {
+                    const uint32_t off = b_off[i] == DMA_OOB ? DMA_OOB : (uint32_t)((int)b_off[i] * pitch + cbase) * 2u;
+                    if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void_ptr)(sb + (pw + F1_NP * i) * 512), 16, off, 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (pw + F1_NP * i) * 512), 16, off, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) {
+                    const uint32_t off = b_off[i] == DMA_OOB ? DMA_OOB : b_off[i] + kb;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_ptr)(sb + (pw + F1_NP * i) * 512), 16, off, 0, 0, 0);
+                }
             }
             ++issued;
             if (++ik == KT) {

@@ -60,6 +60,9 @@ struct IGemmArgs {
     // -a2 (W3^T diag(Q) W3)) become one launch and the partial result is never stored.
     const uint16_t* X2;
     int Ck1;
+    // x_rep (0 = 1; the persistent streaming kernel only): K = x_rep * (Ck1 + c2): each tensor's channels appear x_rep times in a row, against a
+    // split weight image [W1 hi | W1 lo | W2 hi | W2 lo] -- fp32-grade weights (BatchNorm scales folded in) on the bf16 matrix pipe
+    int x_rep;
 };
 
 struct WGradArgs {
@@ -85,6 +88,7 @@ struct BnBwdSide { const uint16_t* raw; const float* mean; const float* invstd; 
 // conv.hip
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a);
 int igemm_conv_stat_tiles(int Cm, int P, int K);
+bool conv_cat_act_supported(int Cm, int c1, int c2, int P, int parts = 1);      // [X | X2] GEMM with the scale / shift / ReLU output stage at this size?
 // taps = R*S of the convolution (1 for 1x1 convolutions and linear layers): selects the tile shape
 // halo_w = output width of a 3x3 / stride 1 / pad 1 convolution whose H*W is a power of two (0 otherwise): enables the halo kernel
 void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pix_per_split, size_t* ws_bytes, int taps = 1, int halo_w = 0);
@@ -132,6 +136,8 @@ int launch_bn_eval_coeffs(hipStream_t st, const float* gamma, const float* beta,
 struct BnEvalJob { const float *gamma, *beta, *rm, *rv; float *scale, *shift; int C; };
 struct BnEvalJobs { static constexpr int MAX = 56; BnEvalJob job[MAX]; };
 int launch_bn_eval_coeffs_batched(hipStream_t st, const BnEvalJob* jobs, int n, float eps);
+int launch_fold_cat_weights(hipStream_t st, const float* w3, const float* wd, const float* s3, const float* sd, const float* h3, const float* hd, int C, int w,
+                            int cin, int parts, uint16_t* wcat, float* shcat);
 int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,
                   const float* scale2, const float* shift2, int relu, size_t elems, int C, uint16_t* y, uint8_t* mask_out);
 int bn_bwd_blocks(int P, int C, int* rows_per_block);

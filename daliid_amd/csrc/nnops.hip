@@ -72,6 +72,25 @@ __global__ void bn_eval_coeffs_batched_kernel(BnEvalJobs jobs, float eps) {
     }
 }
 
+// inference: conv3 and a stride-1 downsample convolution of a bottleneck as ONE GEMM over [a2 | x]: the weight image [C][w + cin] with each
+// BatchNorm's scale folded into its rows (one rounding, from the fp32 master weights) and the summed shifts
+__global__ void fold_cat_weights_kernel(const float* __restrict__ w3, const float* __restrict__ wd, const float* __restrict__ s3, const float* __restrict__ sd,
+                                        const float* __restrict__ h3, const float* __restrict__ hd, int C, int w, int cin, int parts,
+                                        uint16_t* __restrict__ wcat, float* __restrict__ shcat) {
+    // parts == 2: [s3.W3 hi | s3.W3 lo | sd.Wd hi | sd.Wd lo], hi = bf16(v), lo = bf16(v - hi): the folded fp32 weights to ~2^-17
+    const int K = parts * (w + cin);
+    const size_t n = (size_t)C * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e / K), k = (int)(e - (size_t)c * K);
+        const bool first = k < parts * w;
+        const int kk = first ? k : k - parts * w, width = first ? w : cin, part = kk / width, col = kk - part * width;
+        const float v = first ? s3[c] * w3[(size_t)c * w + col] : sd[c] * wd[(size_t)c * cin + col];
+        const uint16_t hi = f32_to_bf16_bits(v);
+        wcat[e] = part == 0 ? hi : f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+        if (k == 0) shcat[c] = h3[c] + hd[c];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block output: y = relu( raw*scale+shift + identity ), identity = idn (bf16) or raw2*scale2+shift2.
 // ------------------------------------------------------------------------------------------------
@@ -856,6 +875,13 @@ int launch_bn_eval_coeffs_batched(hipStream_t st, const BnEvalJob* jobs, int n, 
         hipLaunchKernelGGL(bn_eval_coeffs_batched_kernel, dim3((cmax + 255) / 256, m), dim3(256), 0, st, chunk, eps);
         DALI_LAUNCH_CHECK();
     }
+    return DALI_OK;
+}
+int launch_fold_cat_weights(hipStream_t st, const float* w3, const float* wd, const float* s3, const float* sd, const float* h3, const float* hd, int C, int w,
+                            int cin, int parts, uint16_t* wcat, float* shcat) {
+    const size_t n = (size_t)C * parts * (w + cin);
+    hipLaunchKernelGGL(fold_cat_weights_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, w3, wd, s3, sd, h3, hd, C, w, cin, parts, wcat, shcat);
+    DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 int launch_bn_act(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, const uint16_t* idn, const uint16_t* raw2,

@@ -51,6 +51,10 @@ struct Block {
     bool lin_ds = false;
     float *gram_d = nullptr, *m2_d = nullptr, *ut_d = nullptr, *bvec_d = nullptr, *qk_d = nullptr;   // [cin][cin], [cin], [cin][cout], [cin], [2][cout]
     uint16_t* wdd = nullptr;                                   // [cin][cout + cin]: (A_d.Wd)^T beside -(Wd^T diag(Q_d) Wd)
+    // inference: conv3 + the (stride-1) downsample convolution as one GEMM over [a2 | x] (dali_conv1x1_cat_act): the folded weight image and shift
+    bool cat_eval = false;
+    uint16_t* wcat = nullptr;
+    float* shcat = nullptr;
     uint16_t* dbg_d_raw1 = nullptr;                            // where the last backward of this block left d(raw1) (scratch: valid until the next block runs)
 };
 
@@ -287,6 +291,10 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             max_slab = std::max(max_slab, wsb);
             max_cs = std::max(max_cs, std::max(colsum_partial_floats((int)pin, b.cin), (size_t)wgrad_colsum_rows(b.cin, b.cin, 1, (int)pin, sp) * b.cin) * 4);
         }
+        // (split weight image, 2 parts: folding the scales into ONE bf16 image is a coherent 2^-9 perturbation of the weights, which moved the mAP of
+        //  separated identities by 1.1e-3 against the oracle; hi + lo images are fp32-grade.  K = 2 (w + cin) <= 256: layer1's first block.)
+        b.cat_eval = b.has_ds && b.cd.stride == 1 && b.lin3 && conv_cat_act_supported(b.cout, b.width, b.cin, (int)pout, 2);
+        if (b.cat_eval) { reserve(net, a, b.wcat, (size_t)b.cout * 2 * (b.width + b.cin) * 2); reserve(net, a, b.shcat, (size_t)b.cout * 4); }
         reserve_bn(net, a, b.b1); reserve_bn(net, a, b.b2); reserve_bn(net, a, b.b3);
         if (b.has_ds) reserve_bn(net, a, b.bd);
         Conv* cs[4] = {&b.c1, &b.c2, &b.c3, b.has_ds ? &b.cd : nullptr};
@@ -521,6 +529,21 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                 if ((rc = launch_bnlin_stats(st, b.c3.wt_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
                                              net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.ut, b.dot, b.b3.scale, b.b3.shift, b.b3.mean,
                                              b.b3.invstd))) return rc;
+            }
+            if (!tr && b.cat_eval && eval_fused() && DALI_ENV_INT("DALI_EVAL_CAT", 1) != 0) {
+                // inference, stride-1 downsample branch: y = relu([a2 | x] [s3.W3 | sd.Wd]^T + shift3 + shift_d) in one launch: no raw branch
+                // output, no residual read (the scales ride in a split hi + lo weight image: fp32-grade weights, mirrored by the twin)
+                if ((rc = launch_fold_cat_weights(st, net->P + b.c3.w_off, net->P + b.cd.w_off, b.b3.scale, b.bd.scale, b.b3.shift, b.bd.shift, b.cout, b.width,
+                                                  b.cin, 2, b.wcat, b.shcat))) return rc;
+                IGemmArgs ca{};
+                ca.W = b.wcat; ca.X = b.a2; ca.X2 = x; ca.Ck1 = b.width; ca.x_rep = 2; ca.O = b.y; ca.out_shift = b.shcat; ca.out_relu = 1;
+                ca.Cm = b.cout; ca.P = Pout;
+                Conv cat = b.c3;
+                cat.cin = 2 * (b.width + b.cin);
+                ca.g = conv_geom(cat, 0);
+                if ((rc = launch_igemm_conv(st, ca))) return rc;
+                x = b.y;
+                continue;
             }
             IGemmArgs a{};
             a.W = b.c3.w_bf16; a.X = b.a2; a.O = b.y; a.Res = x; a.out_scale = b.b3.scale; a.out_shift = b.b3.shift; a.out_relu = 1;

@@ -99,6 +99,19 @@ def conv1x1_cat(x1, x2, w, bias=None):
     return y
 
 
+def conv1x1_cat_act(x1, x2, w, out_shift, out_scale=None, relu=True, parts=1):
+    """y [P,cout] = relu?(([x1 | x2] @ w.T) * out_scale + out_shift) in one launch (dali_conv1x1_cat_act); parts = 2: w = [W1 hi | W1 lo | W2 hi | W2 lo]."""
+    P, c1 = x1.shape
+    c2 = x2.shape[1]
+    cout = w.shape[0]
+    assert x2.shape[0] == P and w.shape[1] == parts * (c1 + c2)
+    y = torch.empty(P, cout, device=x1.device, dtype=bf16)
+    _lib.check(_lib.lib().dali_conv1x1_cat_act(_lib.ctx(x1.device), _lib.stream_ptr(), _lib.ptr(x1, bf16, "x1"), c1, _lib.ptr(x2, bf16, "x2"), c2,
+                                                _lib.ptr(w, bf16, "w"), int(parts), _lib.ptr(out_scale), _lib.ptr(out_shift, torch.float32, "out_shift"), int(relu),
+                                                _lib.ptr(y), P, cout), "dali_conv1x1_cat_act")
+    return y
+
+
 def bnlin_fwd(a, w, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """a [P,w] bf16, w [C,w] bf16 -> dict(gram, m2, scale, shift, mean, invstd): training-mode BatchNorm coefficients of a @ w.T"""
     P, wd = a.shape

@@ -165,6 +165,15 @@ int dali_conv1x1_fused(dali_ctx* ctx, void* stream, const uint16_t* x, const uin
  * (autograd of torchvision's Bottleneck tail under Encoders.py:330-339).  c1 % 32 == 0, c2 % 32 == 0, cout % 8 == 0; bias nullable. */
 int dali_conv1x1_cat(dali_ctx* ctx, void* stream, const uint16_t* x1, int c1, const uint16_t* x2, int c2, const uint16_t* w, const float* bias,
                      uint16_t* y, int pixels, int cout);
+/* The same two-operand GEMM with the scale / shift / ReLU output stage: y = relu?( ([x1 | x2] @ w^T) * out_scale[c] + out_shift[c] ) (out_scale
+ * nullable = 1).  The inference forward of a bottleneck with a stride-1 downsample branch as ONE launch: with the two BatchNorms' scales folded
+ * into the weight image w = [s3.W3 | sd.Wd] and out_shift = shift3 + shift_d this is relu(bn3(conv3(a2)) + bnd(convd(x))) (torchvision Bottleneck
+ * under Encoders.py:336-339, eval mode: getFeatures.py:56-67).  c1 % 64 == 0, c2 % 64 == 0, cout % 128 == 0; c1 + c2 <= 256 (any pixel count
+ * with at least two 128 x 128 tiles per CU) or c1 + c2 >= 1024 with cout >= 512 and >= 16384 pixels.
+ * weight_parts = 2: w is [cout][2 (c1 + c2)] = [W1 hi | W1 lo | W2 hi | W2 lo] with hi = bf16(v), lo = bf16(v - hi): folded fp32 weights to ~2^-17
+ * (a single bf16 image of scale-folded weights is a coherent 2^-9 perturbation that the ranking notices); 2 (c1 + c2) <= 256 only. */
+int dali_conv1x1_cat_act(dali_ctx* ctx, void* stream, const uint16_t* x1, int c1, const uint16_t* x2, int c2, const uint16_t* w, int weight_parts,
+                         const float* out_scale, const float* out_shift, int out_relu, uint16_t* y, int pixels, int cout);
 /* Training-mode BatchNorm behind a 1x1 convolution WITHOUT the convolution's output (csrc/bnlin.hip): raw = a W^T is linear in
  * a [P][w] (bf16), so its batch statistics follow from gram = a^T a [w][w] and m2 = colsum(a) [w] (returned, fp32):
  * mean = W m2 / P, E[raw^2] = diag(W gram W^T) / P; ut = (W gram)^T [w][C] (fp32) is returned for the backward, with m2.  Outputs scale = gamma*invstd, shift = beta - mean*scale,

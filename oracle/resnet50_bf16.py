@@ -142,6 +142,30 @@ def _bn_eval(u, uq, bn, eps=1e-5):
     return uq * scale.view(shp) + shift.view(shp)
 
 
+def cat_eval_supported(blk, n_pixels, n_cus=256):
+    """Does the HIP plan run this block's conv3 and downsample convolution as ONE GEMM over [a2 | x] in the inference forward (resnet_plan.hip
+    `cat_eval`, conv.hip conv_cat_act_supported)?  Stride-1 branch, channel counts multiples of 64, and a size one of the two kernels with that
+    size the persistent streaming kernel takes with a split weight image: K = 2 (w + cin) <= 256 and at least two 128 x 128 tiles per CU.
+    ResNet-50 at 256 x 128: layer1's first block."""
+    import os
+    d = blk.downsample
+    if d is None or d[0].stride != (1, 1) or stores_raw3(blk) or os.environ.get("DALI_EVAL_FUSED", "1") == "0" or os.environ.get("DALI_EVAL_CAT", "1") == "0":
+        return False
+    w, cin, C = blk.conv3.in_channels, d[0].in_channels, blk.conv3.out_channels
+    if w % 64 or cin % 64 or C % 128:
+        return False
+    K = 2 * (w + cin)                                   # split (hi + lo) weight images: every channel twice
+    if K > 256:
+        return False
+    tiles_m, tiles_n = C // 128, (n_pixels + 127) // 128
+    return tiles_m * tiles_n >= 2 * n_cus and (n_cus // 8) % tiles_m == 0
+
+
+def _bn_eval_coeffs(bn, eps=1e-5):
+    scale = bn.weight / torch.sqrt(bn.running_var + eps)
+    return scale, bn.bias - bn.running_mean * scale
+
+
 def forward_matched(model, x, training=True):
     """model: oracle.resnet50_reid.ResNet50ReID (its parameters receive the gradients).  training=True: batch statistics (the train
     step); False: running statistics (extractFeatures), same rounding points."""
@@ -160,6 +184,19 @@ def forward_matched(model, x, training=True):
             a1 = Q(F.relu(_bn(u1, Qr(u1), blk.bn1)))
             u2 = _conv(a1, blk.conv2)
             a2 = Q(F.relu(_bn(u2, Qr(u2), blk.bn2)))
+            if not training and cat_eval_supported(blk, a2.shape[0] * a2.shape[2] * a2.shape[3]):
+                # inference, stride-1 downsample branch: one GEMM over [a2 | x] against [s3.W3 | sd.Wd], the BatchNorm scales folded into the weight
+                # image (split in bf16 hi + lo parts, from the fp32 weights) and the shifts summed (resnet_plan.hip cat_eval, fold_cat_weights_kernel)
+                s3, h3 = _bn_eval_coeffs(blk.bn3)
+                sd, hd = _bn_eval_coeffs(blk.downsample[1])
+                def hi_lo(v):                        # the split weight image: hi = bf16(v), lo = bf16(v - hi); the GEMM sees hi + lo
+                    hi = v.to(torch.bfloat16).float()
+                    return hi + (v - hi).to(torch.bfloat16).float()
+                f3 = hi_lo(s3.view(-1, 1, 1, 1) * blk.conv3.weight)
+                fd = hi_lo(sd.view(-1, 1, 1, 1) * blk.downsample[0].weight)
+                x = Q(F.relu(F.conv2d(a2, f3) + F.conv2d(x, fd) + (h3 + hd).view(1, -1, 1, 1)))
+                first = False
+                continue
             if training and not stores_raw3(blk):
                 out = _Conv3Bn3Moments.apply(a2, blk.conv3.weight, blk.bn3.weight, blk.bn3.bias, 1e-5)
             else:

@@ -180,3 +180,35 @@ def test_conv1x1_two_operand_tensors_exact_integers(nn, P, c1, c2, cout):
     assert torch.equal(y.cpu(), ref), (y.cpu().float() - ref.float()).abs().max()
     y0 = nn.conv1x1_cat(x1.to(bf16).cuda(), x2.to(bf16).cuda(), w.to(bf16).cuda())
     assert torch.equal(y0.cpu(), (torch.cat((x1, x2), 1) @ w.t()).to(bf16))
+
+
+# the persistent streaming kernel (K = c1 + c2 <= 256) and the 256 x 256 k-tile-64 kernel (K >= 1024): the plan's layer1.0 / layer4.0 shapes at batch 256
+# and an inference batch (500 images: ragged pixel tiles)
+@pytest.mark.parametrize("P,c1,c2,cout", [(524288, 64, 64, 256), (1024000, 64, 64, 256), (40000, 128, 64, 256), (32768, 512, 1024, 2048), (64000, 512, 1024, 2048)])
+def test_conv1x1_two_operand_tensors_with_output_stage_exact_integers(nn, P, c1, c2, cout):
+    """y = relu(([x1 | x2] @ w^T) * scale + shift) in ONE launch (dali_conv1x1_cat_act: conv3 + a stride-1 downsample branch of the inference forward):
+    small integers, power-of-two scales and integer shifts, so the result equals the fp32 reference rounded once to bf16 bit for bit."""
+    g = torch.Generator().manual_seed(P + c1 + cout + 5)
+    dev = "cuda"
+    x1 = torch.randint(-2, 3, (P, c1), generator=g).to(dev)
+    x2 = torch.randint(-2, 3, (P, c2), generator=g).to(dev)
+    w = torch.randint(-1, 2, (cout, c1 + c2), generator=g).to(dev)
+    w[:, c1:] *= 2
+    shift = torch.randint(-3, 4, (cout,), generator=g).float().to(dev)
+    scale = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (cout,), generator=g)].to(dev)
+    acc = torch.cat((x1, x2), 1).float() @ w.float().T
+    y = nn.conv1x1_cat_act(x1.to(bf16), x2.to(bf16), w.to(bf16), shift, relu=True)
+    assert torch.equal(y, torch.relu(acc + shift).to(bf16))
+    y2 = nn.conv1x1_cat_act(x1.to(bf16), x2.to(bf16), w.to(bf16), shift, out_scale=scale, relu=False)
+    assert torch.equal(y2, (acc * scale + shift).to(bf16))
+    if 2 * (c1 + c2) <= 256:
+        # split weight image [W1 hi | W1 lo | W2 hi | W2 lo] (what the inference forward uses: BatchNorm scales folded into fp32-grade weights): weights with
+        # a fractional part that bf16 cannot hold in one piece -- 1 + 2^-9 steps -- but hi + lo can; products and sums stay exact in fp32
+        wf = w.float() * (1.0 + torch.randint(0, 4, w.shape, generator=g).to(dev) * 2.0 ** -9)
+        hi = wf.to(bf16)
+        lo = (wf - hi.float()).to(bf16)
+        assert torch.equal(hi.float() + lo.float(), wf)
+        w4 = torch.cat((hi[:, :c1], lo[:, :c1], hi[:, c1:], lo[:, c1:]), 1).contiguous()
+        y3 = nn.conv1x1_cat_act(x1.to(bf16), x2.to(bf16), w4, shift, relu=True, parts=2)
+        ref3 = torch.relu((torch.cat((x1, x2), 1).double() @ wf.double().T).float() + shift).to(bf16)
+        assert torch.equal(y3, ref3)
