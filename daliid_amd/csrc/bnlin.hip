@@ -17,6 +17,7 @@
 // The sums are fp32 MFMA accumulations reduced in a fixed order and finished in fp64: deterministic, and closer to the fp32
 // reference than statistics of a bf16-rounded tensor.
 #include "kernels.h"
+#include "reduce_finish.h"
 #include <algorithm>
 
 namespace dali {
@@ -48,11 +49,19 @@ __device__ __forceinline__ float ld_f(const uint16_t* p) { return bf16_bits_to_f
 // Epilogues: C as fp32 [M][ldc]; or bf16 of -C; optionally dot[m-tile][n] = sum_{m in tile} C[m][n] * B2[m][n] (the quadratic form
 // w_c G w_c^T per output channel) and vsum[n] = sum_k v[k] B[k][n] on the m-tile-0 workgroups (W^T Kc).
 // ------------------------------------------------------------------------------------------------
-template <class TA, bool HAS_SA, bool HAS_V>
+// FIN (the forward's product): the LAST workgroup of a column block to arrive (one device-scope counter per block of 32 channels, the arrival
+// pattern of reduce_finish.h: sc1 stores of the partials, every wave's vmcnt(0), barrier, one relaxed atomic) sums the column block's quadratic-
+// form partials over the m tiles in a fixed order, forms mean[c] = W^T[.,c] . m2 / P and finishes scale / shift / mean / invstd (+ running
+// statistics) for its 32 channels: what bnlin_finish_kernel did in a launch of its own (16 launches of 9 us per ResNet step).
+struct BnlinFin {
+    const float* m2; double count; const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps;
+    float *scale, *shift, *mean_out, *invstd_out; unsigned int* ctr; int w;
+};
+template <class TA, bool HAS_SA, bool HAS_V, bool FIN = false>
 __global__ __launch_bounds__(256) void bnlin_tn_gemm_kernel(const TA* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, const float* __restrict__ sa,
                                                              int K, float* __restrict__ Cf, uint16_t* __restrict__ Cneg, int ldc,
                                                              const uint16_t* __restrict__ B2, int ldb2, float* __restrict__ dot, int ldd,
-                                                             const float* __restrict__ v, float* __restrict__ vsum) {
+                                                             const float* __restrict__ v, float* __restrict__ vsum, BnlinFin fin = BnlinFin{}) {
     __shared__ float red[3][16][64];                    // partial accumulators of waves 1..3
     __shared__ float vred[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -118,12 +127,52 @@ __global__ __launch_bounds__(256) void bnlin_tn_gemm_kernel(const TA* __restrict
         }
         if (B2) {
             d += __shfl_xor(d, 32, 64);                 // the two row halves of the tile
-            if (h == 0) dot[(size_t)blockIdx.y * ldd + n0 + i] = d;
+            if (h == 0) {
+                if constexpr (FIN) __hip_atomic_store(&dot[(size_t)blockIdx.y * ldd + n0 + i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: seen by the finishing workgroup on any XCD
+                else dot[(size_t)blockIdx.y * ldd + n0 + i] = d;
+            }
         }
         if (do_v) {
             float t = ((vred[0][lane] + vred[1][lane]) + vred[2][lane]) + vred[3][lane];
             t += __shfl_xor(t, 32, 64);
             if (h == 0) vsum[n0 + i] = t;
+        }
+    }
+    if constexpr (FIN) {
+        __shared__ int s_last;
+        __shared__ double fred[2][8][32];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's sc1 stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(&fin.ctr[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == gridDim.y - 1;
+            if (s_last) __hip_atomic_store(&fin.ctr[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the slot's next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const int cx = threadIdx.x & 31, grp = threadIdx.x >> 5, c = n0 + cx;      // 32 channels x 8 groups over k / over the m tiles, fixed order
+        double mu = 0.0, q = 0.0;
+        for (int k = grp; k < fin.w; k += 8) mu += (double)bf16_bits_to_f32(B[(size_t)k * ldb + c]) * (double)fin.m2[k];
+        for (int t = grp; t < (int)gridDim.y; t += 8) q += (double)__hip_atomic_load(&dot[(size_t)t * ldd + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fred[0][grp][cx] = mu; fred[1][grp][cx] = q;
+        __syncthreads();
+        if (grp == 0) {
+            mu = ((fred[0][0][cx] + fred[0][1][cx]) + (fred[0][2][cx] + fred[0][3][cx])) + ((fred[0][4][cx] + fred[0][5][cx]) + (fred[0][6][cx] + fred[0][7][cx]));
+            q = ((fred[1][0][cx] + fred[1][1][cx]) + (fred[1][2][cx] + fred[1][3][cx])) + ((fred[1][4][cx] + fred[1][5][cx]) + (fred[1][6][cx] + fred[1][7][cx]));
+            const double mean = mu / fin.count;
+            double var = q / fin.count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+            const float sc = fin.gamma[c] * invstd;
+            fin.scale[c] = sc;
+            fin.shift[c] = fin.beta[c] - (float)mean * sc;
+            fin.mean_out[c] = (float)mean;
+            fin.invstd_out[c] = invstd;
+            if (fin.running_mean) {                              // torch's update rule, as bn_finalize_kernel (nnops.hip)
+                const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+                fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean;
+                fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+            }
         }
     }
 }
@@ -231,6 +280,17 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
                        float* mean, float* invstd) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
     // Ut[k'][c] = sum_k G[k][k'] Wt[k][c]  (G symmetric: read as A[k][m = k']); dot[tile][c] = sum_{k' in tile} Ut[k'][c] Wt[k'][c]
+    if (C / 32 <= RF_GROUPS && DALI_ENV_INT("DALI_BNLIN_FUSED_FINISH", 1) != 0) {
+        // the statistics finish in the product's own launch, by the last workgroup of every 32-channel column block (see BnlinFin)
+        unsigned int* ctr = nullptr;
+        if (int rc = rf_counter_base(&ctr)) return rc;
+        ctr += (size_t)rf_next_slot() * RF_GROUPS;
+        const BnlinFin fin{m2, count, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd, ctr, w};
+        hipLaunchKernelGGL((bnlin_tn_gemm_kernel<float, false, false, true>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, Wt, C, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
+                           Wt, C, dot, C, (const float*)nullptr, (float*)nullptr, fin);
+        DALI_LAUNCH_CHECK();
+        return DALI_OK;
+    }
     hipLaunchKernelGGL((bnlin_tn_gemm_kernel<float, false, false>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, Wt, C, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
                        Wt, C, dot, C, (const float*)nullptr, (float*)nullptr);
     DALI_LAUNCH_CHECK();
