@@ -44,6 +44,8 @@ _SIGNATURES = {
     "dali_rank_shard_finish": [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6,
     "dali_conv2d_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p],
     "dali_conv2d_bn_act": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int],
+    "dali_stem_fused_supported": [c_int, c_int, c_int],
+    "dali_stem_conv_bn_maxpool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "dali_conv2d_stat_tiles": [c_int] * 10,
     "dali_conv2d_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9,
     "dali_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_int],

@@ -1853,7 +1853,8 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * 128, ci0 = tn * 64;
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12] = __builtin_amdgcn_s_memrealtime();
-    const bool m_active = m0 + wm * 64 < a.Cm;          // Cout = 64: the upper half of the co tile is padding, its waves only help with the DMA
+    const bool m_active = m0 + wm * 64 < a.Cm && a.ablate != 2;          // Cout = 64: the upper half of the co tile is padding, its waves only help with the DMA
+    const bool feed = a.ablate != 1;
     const GatherGeom g = a.g;
     const int W = g.Wout, H = g.Hout, Cin = g.Ck, lw = g.lw, lhw = g.lhw;
     const int RW = 32 >> lw, HC = W + 2, HP = (RW + 2) * HC;
@@ -1940,7 +1941,7 @@ __global__ __launch_bounds__(512) void igemm_wgrad3x3_kernel(WGradArgs a, int ti
         if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 12 + 1] = __builtin_amdgcn_s_memrealtime();
         int st_cur = 0, st_fill = AHEAD % NSTAGE;
         for (int kt = 0; kt < ksteps; ++kt) {
-            if (kt + AHEAD < ksteps) issue(kt + AHEAD, st_fill);
+            if (kt + AHEAD < ksteps && feed) issue(kt + AHEAD, st_fill);
             const uint16_t* sa = smem + st_cur * W3_STAGE;
             const uint16_t* sb = sa + W3_A_ELEMS;
             if (m_active) {
@@ -3015,6 +3016,7 @@ void wgrad_plan(int Cm, int Ntot, int P, int target_blocks, int* splits, int* pi
 int launch_igemm_wgrad(hipStream_t st, const WGradArgs& a, float* out, int accumulate, float* colsum_out, int colsum_rows) {
     WGradArgs args = a;
     args.stamps = g_conv_stamps;
+    args.ablate = DALI_ENV_INT("DALI_WGRAD_ABLATE", 0);
     args.g.lw = ilog2_exact(a.g.Wout);
     args.g.lhw = ilog2_exact(a.g.Hout * a.g.Wout);
     const int tiles_m = (a.Cm + 127) / 128, tiles_n = (a.Ntot + 127) / 128;

@@ -74,6 +74,8 @@ struct WGradArgs {
     int splits, pix_per_split;    // pix_per_split multiple of 32
     GatherGeom g;
     unsigned long long* stamps;   // diagnostic, as in IGemmArgs
+    int ablate;                   // diagnostic (DALI_WGRAD_ABLATE, igemm_wgrad3x3_kernel): 1 = no operand requests after the ring's prologue (the k-steps keep
+                                  // their reads, MFMAs and barriers), 2 = requests and barriers only (no fragment reads, no MFMAs); results are wrong
     float* colsum;                // optional [splits][Cm]: per-split column sums over the pixels of dY, by one extra MFMA per fragment against a
                                   // ones operand in the n-tile-0 workgroups (128 x 128 kernel only: wgrad_colsum_supported); bnlin.hip's s / m2
 };
@@ -147,6 +149,10 @@ int launch_bn_bwd(hipStream_t st, const uint16_t* g, const uint16_t* ymask, cons
                   uint16_t* draw_a, uint16_t* draw_b, uint16_t* dz_out, double* scratch);
 int launch_stem_pack_image(hipStream_t st, const float* img, int N, int H, int W, uint16_t* out);
 int launch_stem_pack_weight(hipStream_t st, const float* w, int Cout, uint16_t* out);
+// stem.hip: the inference stem (conv1 -> bn1 by running statistics -> 3x3 / 2 max-pool) in one launch, packed image -> pooled [N][H/4][W/4][64]
+bool stem_fused_supported(int N, int H, int W, int C);
+int launch_stem_conv_bn_pool(hipStream_t st, const uint16_t* ximg, const uint16_t* w_packed, const float* scale, const float* shift, int N, int H, int W,
+                             uint16_t* out);
 int launch_stem_unpack_wgrad(hipStream_t st, const float* padded, int Cout, float* dw);
 int launch_maxpool_bn_fwd(hipStream_t st, const uint16_t* raw, const float* scale, const float* shift, int N, int H, int W, int C,
                           uint16_t* out, uint8_t* arg);

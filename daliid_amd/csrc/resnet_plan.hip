@@ -486,6 +486,10 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
     }
     // ---- stem: conv1 -> bn1 -> (no ReLU) -> maxpool ----
     if ((rc = launch_stem_pack_image(st, images, net->N, net->H, net->W, net->ximg))) return rc;
+    if (!tr && eval_fused() && stem_fused_supported(net->N, net->H, net->W, net->stem.cout)) {
+        // inference: one launch, the convolution's output never stored (stem.hip); bn1 acts on the fp32 accumulators
+        if ((rc = launch_stem_conv_bn_pool(st, net->ximg, net->w_stem, net->stem_bn.scale, net->stem_bn.shift, net->N, net->H, net->W, net->pool0))) return rc;
+    } else {
     {
         IGemmArgs a{};
         a.W = net->w_stem; a.X = net->ximg; a.O = net->raw0; a.Res = nullptr; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
@@ -497,6 +501,7 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
     }
     if ((rc = launch_maxpool_bn_fwd(st, net->raw0, net->stem_bn.scale, net->stem_bn.shift, net->N, net->stem_h, net->stem_w, net->stem.cout,
                                     net->pool0, net->pool_arg))) return rc;
+    }
     // ---- bottleneck trunk ----
     const uint16_t* x = net->pool0;
     for (auto& b : net->blocks) {

@@ -42,6 +42,19 @@ def conv2d_bn_act(x, w, scale, shift, stride=1, pad=0, relu=True):
     return y
 
 
+def stem_conv_bn_maxpool(images, weight, scale, shift):
+    """maxpool3x3/2(conv7x7/2(images) * scale[c] + shift[c]) in ONE launch (dali_stem_conv_bn_maxpool: the inference stem, no ReLU before the pool):
+    images fp32 [N,3,H,W], weight fp32 [64,7,7,3], scale / shift fp32 [64] -> bf16 [N,H/4,W/4,64]."""
+    n, c, h, w = images.shape
+    if c != 3 or tuple(weight.shape) != (64, 7, 7, 3):
+        raise _lib.DaliError("stem_conv_bn_maxpool: images [N,3,H,W] and weight [64,7,7,3] expected, got %s / %s" % (tuple(images.shape), tuple(weight.shape)))
+    y = torch.empty(n, h // 4, w // 4, 64, device=images.device, dtype=bf16)
+    _lib.check(_lib.lib().dali_stem_conv_bn_maxpool(_lib.ctx(images.device), _lib.stream_ptr(), _lib.ptr(images, torch.float32, "images"), n, h, w,
+                                                     _lib.ptr(weight, torch.float32, "weight"), _lib.ptr(scale, torch.float32, "scale"),
+                                                     _lib.ptr(shift, torch.float32, "shift"), _lib.ptr(y)), "dali_stem_conv_bn_maxpool")
+    return y
+
+
 def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, residual=None, inplace=False, residual_mask=None):
     """dy [N,Ho,Wo,Cout] bf16, wt [Cin,R,S,Cout] bf16 -> dx [N,H,W,Cin] bf16 (+ residual).  ``inplace``: accumulate into
     ``residual`` itself (residual == dx; what the net plan does for the downsample branch).  ``residual_mask``: uint8

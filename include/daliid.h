@@ -150,6 +150,14 @@ int dali_conv2d_fwd(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16
  * shift = beta - running_mean * scale (getFeatures.py:56-67 forwards in eval mode).  cin % 32 == 0, cout % 8 == 0, stride 1 or 2. */
 int dali_conv2d_bn_act(dali_ctx* ctx, void* stream, const uint16_t* x, const uint16_t* w, uint16_t* y, int n, int h, int wd, int cin, int cout,
                        int r, int s, int stride, int pad, const float* out_scale, const float* out_shift, int out_relu);
+/* The inference stem in one launch: y = maxpool3x3/2( conv7x7/2(images) * scale[c] + shift[c] ), images fp32 NCHW [n,3,h,w], weight fp32
+ * [64][7][7][3] (the net's storage order of the logical OIHW tensor), scale / shift fp32 [64] (bn1 by running statistics; NO ReLU between them and
+ * the pool: Encoders.py:321-322, :334), y bf16 NHWC [n, h/4, w/4, 64].  torchvision's conv1 / bn1 / maxpool under Encoders.py:33,36 as
+ * getFeatures.py:56-67 forwards them (eval mode): the convolution's output is never stored, the affine acts on the fp32 accumulators.
+ * h % 32 == 0, w % 32 == 0, w <= 128 (dali_stem_fused_supported; DALI_ERR_INVALID otherwise -- the net plan then runs the three-launch form). */
+int dali_stem_fused_supported(int n, int h, int w);
+int dali_stem_conv_bn_maxpool(dali_ctx* ctx, void* stream, const float* images, int n, int h, int w, const float* weight, const float* scale,
+                              const float* shift, uint16_t* y);
 /* 1x1 convolution (a [pixels][cin] x [cout][cin]^T GEMM) with the fused output stage:
  *   y = gate_{out_mask}( relu?( acc * out_scale[c] + out_shift[c] + bias[c] + res_scale[c] * residual ) ),  bits_out = (y > 0), 1 bit per
  *   element (res_scale: the downsample branch's BatchNorm scale when the residual is its raw convolution output).

@@ -1,0 +1,80 @@
+"""GPU parity of the one-launch inference stem (daliid_amd/csrc/stem.hip, C ABI dali_stem_conv_bn_maxpool): conv1 7x7 / 2 -> bn1 by running
+statistics (no ReLU: Encoders.py:321-322, :334) -> 3x3 / 2 max-pool, torchvision's conv1 / bn1 / maxpool under Encoders.py:33,36 as
+getFeatures.py:56-67 forwards them.
+
+Integer images / weights / shifts and power-of-two scales of both signs: bf16 holds the operands exactly, fp32 holds every sum exactly, so
+the affine result is an exact fp32 number, its bf16 rounding is the one torch's `.to(bfloat16)` makes, and the pooled tensor must equal torch's
+CPU fp32 convolution + affine + rounding + max_pool2d BIT FOR BIT -- at image borders (windows clamped inside the kernel), for negative scales
+(the maximum is taken after the affine, not before), with more tiles than resident workgroups (the persistent loop and its register-staged
+prefetch) and at the benchmarked 256 x 128 size."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+bf16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def nn():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from daliid_amd import ops_nn
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    return ops_nn
+
+
+def _reference(img, w_ohwi, scale, shift):
+    z = F.conv2d(img, w_ohwi.permute(0, 3, 1, 2).contiguous(), stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    return F.max_pool2d(z.to(bf16).float(), 3, 2, 1).permute(0, 2, 3, 1).contiguous()        # NHWC
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 64, 32), (5, 96, 64), (2, 256, 128), (40, 256, 128), (1, 32, 128)])
+def test_stem_conv_bn_maxpool_exact_integers(nn, n, h, w):
+    from daliid_amd import _lib
+    assert _lib.lib().dali_stem_fused_supported(n, h, w) == 1
+    g = torch.Generator().manual_seed(1000 * n + h + w)
+    img = torch.randint(-3, 4, (n, 3, h, w), generator=g).float()
+    wt = torch.randint(-2, 3, (64, 7, 7, 3), generator=g).float()
+    scale = torch.tensor([0.25, -0.5, 1.0, -0.125])[torch.randint(0, 4, (64,), generator=g)]
+    shift = torch.randint(-40, 41, (64,), generator=g).float()
+    want = _reference(img, wt, scale, shift)
+    got = nn.stem_conv_bn_maxpool(img.cuda(), wt.cuda(), scale.cuda(), shift.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == (n, h // 4, w // 4, 64) and got.dtype == bf16
+    assert torch.equal(got.float().cpu(), want)
+    # every output row / column / channel position differs from a constant (a stuck tile or channel block would pass a sum check, not this)
+    assert want.std() > 1.0
+
+
+def test_unsupported_shapes_are_refused_not_approximated(nn):
+    from daliid_amd import _lib
+    assert _lib.lib().dali_stem_fused_supported(4, 64, 48) == 0          # 24 convolution columns: not whole groups of 16
+    assert _lib.lib().dali_stem_fused_supported(4, 64, 256) == 0         # wider than the register-staged patch covers
+    img = torch.zeros(4, 3, 64, 48, device="cuda")
+    with pytest.raises(_lib.DaliError):
+        nn.stem_conv_bn_maxpool(img, torch.zeros(64, 7, 7, 3, device="cuda"), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"))
+
+
+def test_net_plan_inference_stem_equals_the_three_launch_form_up_to_the_raw_rounding():
+    """dali_resnet_forward(training = 0) takes the one-launch stem; DALI_EVAL_STEM=0 keeps conv -> (stored bf16) -> bn + pool.  The two differ by
+    the rounding of the stored convolution output only: pooled tensors agree to one bf16 step of the larger magnitude, and on integer-valued
+    weights / images with unit BatchNorm they are identical."""
+    from daliid_amd import Encoders, _lib
+    net = Encoders.ResNet50ReID(seed=5).eval()
+    x = torch.randn(6, 3, 64, 32, device="cuda")
+    outs = {}
+    for flag in ("1", "0"):
+        os.environ["DALI_EVAL_STEM"] = flag
+        _lib.lib().dali_debug_reload_env()
+        with torch.no_grad():
+            net(x)
+        outs[flag] = net.debug_tensor("pool0", bf16, (6, 16, 8, 64)).float().clone()
+    os.environ.pop("DALI_EVAL_STEM")
+    _lib.lib().dali_debug_reload_env()
+    a, b = outs["1"], outs["0"]
+    assert a.shape == b.shape and a.abs().max() > 0
+    assert ((a - b).abs() <= 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-30).all()
+    assert (a != b).float().mean() < 0.5
