@@ -11,9 +11,12 @@
 //     (8 taps x 4 channels) are the 64 contiguous bytes at patch row 2 row + r, byte 16 col -- no im2col expansion anywhere;
 //   * the weights (64 x 7 x 32) live in registers as 28 A fragments per lane, with the channel order chosen so that a lane's 16 accumulators
 //     are 16 CONTIGUOUS channels of one pixel;
-//   * bn1's scale / shift act on the fp32 accumulators, the bf16 results of the 5 convolution rows go to an LDS tile as order-preserving
-//     16-bit keys, and the pool is nine packed integer maxima per 8 channels.
-// Two 4-wave workgroups per CU: one's pool / staging runs under the other's MFMAs.
+//   * the bf16 results of the 5 convolution rows go to an LDS tile as order-preserving 16-bit keys of sign(scale) * raw, the pool is nine
+//     packed integer maxima per 8 channels, and bn1's scale / shift act on the selected element only.
+// Two 4-wave workgroups per CU (256 registers per wave: the weights alone take 112).  Measured at batch 500 (scripts/bench_stem.py, the
+// kernel's DALI_STEM_ABLATE switches): 170-190 us against 296 + 168 us of the convolution + pool launches; per tile the MFMA pipe (2240 cycles),
+// the LDS port (270 KB = 2100 cycles: 140 KB of B fragments, 74 KB of pool reads, 40 KB of tile writes, 16 KB of patch) and the vector ALU
+// (~2500 cycles of keys, maxima and index arithmetic) each need ~60 us and two waves per SIMD overlap them only in part.
 #include "common.h"
 #include "kernels.h"
 #include "gemm_tile.h"
@@ -41,6 +44,8 @@ struct StemArgs {
     const float* scale; const float* shift;      // bn1 by running statistics
     uint16_t* out;            // [N][Ho][Wo][64]
     int N, Hp, Wp, Wc, Ho, Wo, tiles;            // Wc = 2 Wo convolution columns; tiles = N * Ho / 2
+    int lwo;                  // log2(Wo): W is 32, 64 or 128
+    int ablate;               // diagnostic (DALI_STEM_ABLATE, results wrong): 1 no pool stage, 2 no output stage of the groups, 4 no MFMAs, 8 no prefetch requests
 };
 
 constexpr int SF_THREADS = 256, SF_NST = 4, SF_PATCH_ROWS = 15, SF_CONV_ROWS = 5;
@@ -52,8 +57,9 @@ __global__ __launch_bounds__(SF_THREADS, 2) void stem_conv_bn_pool_kernel(StemAr
     const int q = lane >> 4, n16 = lane & 15;
     const int row_bytes = a.Wp * 8;
     const int patch_bytes = SF_PATCH_ROWS * row_bytes, nchunks = patch_bytes >> 4;
-    unsigned char* patch = sf_smem;
-    unsigned char* ctile = sf_smem + ((patch_bytes + 127) & ~127);
+    constexpr int patch_pitch = SF_THREADS * SF_NST * 16;      // every staged register has a slot (requests past the patch return zeros into the padding):
+                                                               // a register left unwritten behind a branch would still be waited for at the next request
+    unsigned char* ctile = sf_smem + 2 * patch_pitch;              // [patch 0 | patch 1 | convolution tile | pool coefficients]
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.ximg), 0, a.N * a.Hp * row_bytes, 0x00020000);
 
     // A fragments: fragment (i, r) row m is channel 16 (m >> 2) + 4 i + (m & 3), so that accumulator (i, j) of lane group q is channel 16 q + 4 i + j
@@ -65,17 +71,27 @@ __global__ __launch_bounds__(SF_THREADS, 2) void stem_conv_bn_pool_kernel(StemAr
             const int co = 16 * (n16 >> 2) + 4 * i + (n16 & 3);
             A[i][r] = *reinterpret_cast<const bf16x8_t*>(a.w + co * 224 + r * 32 + q * 8);
         }
-    float sc[16], sh[16];
+    // bn1 acts in the POOL stage, on the selected element only (a fifth of the convolution pixels): z = raw * scale + shift is monotone in raw, rising
+    // or falling with the sign of scale, so the tile holds sign(scale) * raw (bf16, as order-preserving keys), the pool takes the maximum of that
+    // and bn1 is applied to the one value it selects.  Bit for bit the three-launch form: bf16(raw) -> raw * scale + shift -> max -> bf16.
+    // (first form: the affine on every accumulator with the 32 coefficients read from LDS per group -- 8 KB per group next to 7 KB of B fragments,
+    //  the LDS port was the bound: 430 KB per tile against 2240 MFMA cycles.)
+    uint32_t sflip[8];                                  // sign bits to flip in the packed pairs (channels 16 q + 2 p, + 1) of this lane's accumulators
 #pragma unroll
-    for (int e = 0; e < 16; e += 4) {
-        const float4 s4 = *reinterpret_cast<const float4*>(a.scale + 16 * q + e), h4 = *reinterpret_cast<const float4*>(a.shift + 16 * q + e);
-        sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
-        sh[e] = h4.x; sh[e + 1] = h4.y; sh[e + 2] = h4.z; sh[e + 3] = h4.w;
-    }
+    for (int p = 0; p < 8; ++p)
+        sflip[p] = (a.scale[16 * q + 2 * p] < 0.f ? 0x8000u : 0u) | (a.scale[16 * q + 2 * p + 1] < 0.f ? 0x80000000u : 0u);
+    // the pool stage's coefficients [|scale| 64 | shift 64] behind the tile (64 bytes per pooled item; in registers they pushed the B-fragment prefetch out)
+    float* coef = reinterpret_cast<float*>(ctile + SF_CONV_ROWS * a.Wc * 128);
+    if (tid < 64) { coef[tid] = fabsf(a.scale[tid]); coef[64 + tid] = a.shift[tid]; }
 
     const int tiles_per_img = a.Ho >> 1;
     // the patch of tile t: packed rows 4 i0 - 2 .. 4 i0 + 12 of image n, one contiguous range (rows -2, -1 of the first tile of an image only feed
     // convolution row -1, which the pool never reads: whatever lies there -- zeros before the buffer, the previous image's last rows -- is unused)
+    // Order inside a turn: convolution rows of tile t -> the registers holding tile t + 1 into the OTHER patch buffer -> requests of tile t + 2 into
+    // the same registers -> pool of tile t (stores).  vmcnt retires in order and the compiler cannot count the pool's stores: whatever it waits for
+    // must not sit right behind them.  Here the registers are consumed a whole convolution stage after the stores before them were issued, and the
+    // new requests start from an empty queue (requests at the top of the turn were made to wait for the previous turn's stores; one patch buffer,
+    // registers consumed after the pool: the same, one store latency per tile).
     auto request = [&](int t, uint4 (&st)[SF_NST]) {
         const int n = t / tiles_per_img, i0 = (t - n * tiles_per_img) * 2;
         const int base = (n * a.Hp + 4 * i0 - 2) * row_bytes;
@@ -86,54 +102,89 @@ __global__ __launch_bounds__(SF_THREADS, 2) void stem_conv_bn_pool_kernel(StemAr
             st[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
         }
     };
+    auto deposit = [&](unsigned char* patch, const uint4 (&st)[SF_NST]) {
+#pragma unroll
+        for (int s = 0; s < SF_NST; ++s) *reinterpret_cast<uint4*>(patch + (tid + SF_THREADS * s) * 16) = st[s];
+    };
     uint4 st[SF_NST];
     int t = blockIdx.x;
-    if (t < a.tiles) request(t, st);
-    const int gpr = a.Wc >> 4, ngroups = SF_CONV_ROWS * gpr;
-    for (; t < a.tiles; t += gridDim.x) {
+    if (t < a.tiles) { request(t, st); deposit(sf_smem, st); }
+    if (t + (int)gridDim.x < a.tiles) request(t + gridDim.x, st);
+    // the weight fragments have landed before the loop (the compiler otherwise waits for them lazily INSIDE it, with counts that also cover the requests)
 #pragma unroll
-        for (int s = 0; s < SF_NST; ++s) {
-            const int c = tid + SF_THREADS * s;
-            if (c < nchunks) *reinterpret_cast<uint4*>(patch + c * 16) = st[s];
-        }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) asm volatile("" : "+v"(A[i][r]));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(sflip[c]));
+    const int lgpr = a.lwo - 3, ngroups = SF_CONV_ROWS << lgpr;        // 16-pixel groups per convolution row: Wc / 16 = Wo / 8
+    int buf = 0;
+    for (; t < a.tiles; t += gridDim.x, buf ^= 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + (int)gridDim.x < a.tiles) request(t + gridDim.x, st);
+        const unsigned char* patch = sf_smem + buf * patch_pitch;
+        const bool more = t + (int)gridDim.x < a.tiles;
         // ---- the 5 convolution rows of this tile, 16 pixels x 64 channels per wave and turn ----
+        auto b_base = [&](int g) -> const unsigned char* {
+            const int cr = g >> lgpr, wc0 = (g - (cr << lgpr)) * 16;
+            return patch + (2 * cr) * row_bytes + (wc0 + n16 + q) * 16;
+        };
+        // the first two tap rows' fragments of a group are requested under the previous group's MFMAs (one LDS round trip per group was exposed;
+        // all seven ahead did not fit the 256 registers beside the 112 of the weights)
+        bf16x8_t B[7];
+        if (wave < ngroups) {
+            const unsigned char* b0 = b_base(wave);
+            B[0] = *reinterpret_cast<const bf16x8_t*>(b0);
+            B[1] = *reinterpret_cast<const bf16x8_t*>(b0 + row_bytes);
+        }
         for (int g = wave; g < ngroups; g += 4) {
-            const int cr = g / gpr, wc0 = (g - cr * gpr) * 16;
-            const unsigned char* b0 = patch + (2 * cr) * row_bytes + (wc0 + n16 + q) * 16;
-            bf16x8_t B[7];
+            const int cr = g >> lgpr, wc0 = (g - (cr << lgpr)) * 16;
+            {
+                const unsigned char* b0 = b_base(g);
 #pragma unroll
-            for (int r = 0; r < 7; ++r) B[r] = *reinterpret_cast<const bf16x8_t*>(b0 + r * row_bytes);
+                for (int r = 2; r < 7; ++r) B[r] = *reinterpret_cast<const bf16x8_t*>(b0 + r * row_bytes);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // all requests before the first MFMA (the scheduler otherwise issues them in pairs, each pair's latency exposed)
             f32x4_t acc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (!(a.ablate & 4)) {
 #pragma unroll
             for (int r = 0; r < 7; ++r)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][r], B[r], acc[i], 0, 0, 0);
+            }
+            if (g + 4 < ngroups) {
+                const unsigned char* b0 = b_base(g + 4);
+                B[0] = *reinterpret_cast<const bf16x8_t*>(b0);
+                B[1] = *reinterpret_cast<const bf16x8_t*>(b0 + row_bytes);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const int px = cr * a.Wc + wc0 + n16;
+            if (!(a.ablate & 2)) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint32_t k[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int e = 8 * h + 2 * p;
-                    const float z0 = fmaf(acc[e >> 2][e & 3], sc[e], sh[e]), z1 = fmaf(acc[(e + 1) >> 2][(e + 1) & 3], sc[e + 1], sh[e + 1]);
-                    k[p] = order_key2(pack_bf16x2(z0, z1));
+                    k[p] = order_key2(pack_bf16x2(acc[e >> 2][e & 3], acc[(e + 1) >> 2][(e + 1) & 3]) ^ sflip[4 * h + p]);
                 }
                 *reinterpret_cast<uint4*>(ctile + px * 128 + (((2 * q + h) ^ (px & 7)) << 4)) = make_uint4(k[0], k[1], k[2], k[3]);
+            }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (more) deposit(sf_smem + (buf ^ 1) * patch_pitch, st);
+        if (t + 2 * (int)gridDim.x < a.tiles && !(a.ablate & 8)) request(t + 2 * gridDim.x, st);
+        asm volatile("" ::: "memory");             // (the compiler otherwise sinks these LDS writes below the pool's stores)
         // ---- 3x3 / stride 2 max-pool of the tile: window rows / columns outside the image are clamped onto a neighbour inside the window ----
         const int n = t / tiles_per_img, i0 = (t - n * tiles_per_img) * 2;
         const int items = 2 * a.Wo * 8;
-        for (int it = tid; it < items; it += SF_THREADS) {
+        for (int it = tid; it < items && !(a.ablate & 1); it += SF_THREADS) {
             const int cc = it & 7, pix = it >> 3;
-            const int pr = pix / a.Wo, pc = pix - pr * a.Wo;
+            const int pr = pix >> a.lwo, pc = pix - (pr << a.lwo);
             int tr[3] = {2 * pr, 2 * pr + 1, 2 * pr + 2};
             if (i0 + pr == 0) tr[0] = 1;
             int tc[3] = {2 * pc - 1, 2 * pc, 2 * pc + 1};
@@ -149,7 +200,22 @@ __global__ __launch_bounds__(SF_THREADS, 2) void stem_conv_bn_pool_kernel(StemAr
             uint4 m = max_key8(max_key8(max_key8(v[0], v[1]), max_key8(v[2], v[3])), max_key8(max_key8(v[4], v[5]), max_key8(v[6], v[7])));
             m = max_key8(m, v[8]);
             const size_t o = (((size_t)n * a.Ho + i0 + pr) * a.Wo + pc) * 64 + cc * 8;
-            *reinterpret_cast<uint4*>(a.out + o) = make_uint4(order_key2(m.x), order_key2(m.y), order_key2(m.z), order_key2(m.w));
+            const uint32_t sel[4] = {order_key2(m.x), order_key2(m.y), order_key2(m.z), order_key2(m.w)};        // sign(scale) * raw of the selected elements
+            float psc[8], psh[8];
+#pragma unroll
+            for (int c = 0; c < 8; c += 4) {
+                const float4 s4 = *reinterpret_cast<const float4*>(coef + 8 * cc + c), h4 = *reinterpret_cast<const float4*>(coef + 64 + 8 * cc + c);
+                psc[c] = s4.x; psc[c + 1] = s4.y; psc[c + 2] = s4.z; psc[c + 3] = s4.w;
+                psh[c] = h4.x; psh[c + 1] = h4.y; psh[c + 2] = h4.z; psh[c + 3] = h4.w;
+            }
+            uint32_t zz[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                // |sign(scale) * raw| = |raw|, and its sign times the sign of scale is raw's: raw * scale = (sign(scale) raw) * |scale|, exactly
+                const float r0 = bf16_bits_to_f32(sel[p] & 0xffffu), r1 = bf16_bits_to_f32(sel[p] >> 16);
+                zz[p] = pack_bf16x2(r0 * psc[2 * p] + psh[2 * p], r1 * psc[2 * p + 1] + psh[2 * p + 1]);
+            }
+            *reinterpret_cast<uint4*>(a.out + o) = make_uint4(zz[0], zz[1], zz[2], zz[3]);
         }
     }
 }
@@ -168,7 +234,7 @@ int stem_cu_count() {
 
 // 64 output channels, an input the packed-row staging covers with 4 requests per thread, a pixel grid in whole groups of 16 columns
 bool stem_fused_supported(int N, int H, int W, int C) {
-    if (C != 64 || H % 32 != 0 || W % 32 != 0 || W > 128) return false;
+    if (C != 64 || H % 32 != 0 || !(W == 32 || W == 64 || W == 128)) return false;
     const int Wp = W + 8, Hp = H + 6;
     if (SF_PATCH_ROWS * Wp * 8 / 16 > SF_THREADS * SF_NST) return false;
     if ((long long)N * Hp * Wp * 8 >= 0x7ff00000ll) return false;
@@ -182,11 +248,13 @@ int launch_stem_conv_bn_pool(hipStream_t st, const uint16_t* ximg, const uint16_
     a.ximg = ximg; a.w = w; a.scale = scale; a.shift = shift; a.out = out;
     a.N = N; a.Hp = H + 6; a.Wp = W + 8; a.Wc = W / 2; a.Ho = H / 4; a.Wo = W / 4;
     a.tiles = N * (a.Ho / 2);
-    const int patch = ((SF_PATCH_ROWS * a.Wp * 8 + 127) & ~127), lds = patch + SF_CONV_ROWS * a.Wc * 128;
+    a.lwo = W == 32 ? 3 : (W == 64 ? 4 : 5);
+    const int lds = 2 * SF_THREADS * SF_NST * 16 + SF_CONV_ROWS * a.Wc * 128 + 512;
+    a.ablate = DALI_ENV_INT("DALI_STEM_ABLATE", 0);
     DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_bn_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)));
     const int n_cus = stem_cu_count();
     if (n_cus <= 0) { set_error("stem_conv_bn_pool: device query failed"); return DALI_ERR_HIP; }
-    const int grid = a.tiles < 2 * n_cus ? a.tiles : 2 * n_cus;
+    const int grid = a.tiles < 2 * n_cus ? a.tiles : 2 * n_cus;          // two resident workgroups per CU (1: 258 us, 2: 177, 3: 190 at batch 500)
     hipLaunchKernelGGL(stem_conv_bn_pool_kernel, dim3(grid), dim3(SF_THREADS), lds, st, a);
     DALI_LAUNCH_CHECK();
     return DALI_OK;

@@ -153,8 +153,9 @@ int dali_conv2d_bn_act(dali_ctx* ctx, void* stream, const uint16_t* x, const uin
 /* The inference stem in one launch: y = maxpool3x3/2( conv7x7/2(images) * scale[c] + shift[c] ), images fp32 NCHW [n,3,h,w], weight fp32
  * [64][7][7][3] (the net's storage order of the logical OIHW tensor), scale / shift fp32 [64] (bn1 by running statistics; NO ReLU between them and
  * the pool: Encoders.py:321-322, :334), y bf16 NHWC [n, h/4, w/4, 64].  torchvision's conv1 / bn1 / maxpool under Encoders.py:33,36 as
- * getFeatures.py:56-67 forwards them (eval mode): the convolution's output is never stored, the affine acts on the fp32 accumulators.
- * h % 32 == 0, w % 32 == 0, w <= 128 (dali_stem_fused_supported; DALI_ERR_INVALID otherwise -- the net plan then runs the three-launch form). */
+ * getFeatures.py:56-67 forwards them (eval mode): the convolution's output is never stored; rounding points as if it were (bf16 of the
+ * convolution's output, fp32 affine, bf16 of the pooled value), so the result equals conv -> bf16 -> affine -> max-pool -> bf16 bit for bit.
+ * h % 32 == 0, w in {32, 64, 128} (dali_stem_fused_supported; DALI_ERR_INVALID otherwise -- the net plan then runs the three-launch form). */
 int dali_stem_fused_supported(int n, int h, int w);
 int dali_stem_conv_bn_maxpool(dali_ctx* ctx, void* stream, const float* images, int n, int h, int w, const float* weight, const float* scale,
                               const float* shift, uint16_t* y);

@@ -161,16 +161,6 @@ def cat_eval_supported(blk, n_pixels, n_cus=256):
     return tiles_m * tiles_n >= 2 * n_cus and (n_cus // 8) % tiles_m == 0
 
 
-def stem_fused_supported(model, x):
-    """Does the HIP plan run the inference stem as ONE launch (stem.hip: conv1 -> bn1 on the fp32 accumulators -> max-pool; stem_fused_supported)?
-    64 stem channels, H % 32 == 0, W % 32 == 0, W <= 128."""
-    import os
-    if os.environ.get("DALI_EVAL_FUSED", "1") == "0" or os.environ.get("DALI_EVAL_STEM", "1") == "0":
-        return False
-    h, w = x.shape[-2:]
-    return model.conv1.out_channels == 64 and h % 32 == 0 and w % 32 == 0 and w <= 128
-
-
 def _bn_eval_coeffs(bn, eps=1e-5):
     scale = bn.weight / torch.sqrt(bn.running_var + eps)
     return scale, bn.bias - bn.running_mean * scale
@@ -185,8 +175,8 @@ def forward_matched(model, x, training=True):
     Qr = Q if training else (lambda t: t)
     x = Q(x)
     u = _conv(x, model.conv1)
-    # (the inference stem in one launch: bn1 acts on the fp32 accumulators, the convolution's output is never stored)
-    z = _bn(u, u if (not training and stem_fused_supported(model, x)) else Q(u), model.bn1)                   # no ReLU after the stem BN (Encoders.py:334)
+    # (inference runs the stem in one launch, stem.hip, with these rounding points: bf16 of the convolution's output, fp32 affine, bf16 of the pooled value)
+    z = _bn(u, Q(u), model.bn1)                   # no ReLU after the stem BN (Encoders.py:334)
     x = Q(F.max_pool2d(z, 3, 2, 1))
     first = True
     for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
