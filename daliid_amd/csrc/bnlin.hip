@@ -41,14 +41,18 @@ __device__ __forceinline__ float ld_f(const uint16_t* p) { return bf16_bits_to_f
 // ------------------------------------------------------------------------------------------------
 // The two small products of the scheme, W G ([C][w] x [w][w]) and W^T diag(Q) W ([w][C] x [C][w]): 0.5 GMAC each at layer4, exact fp32
 // wanted (they carry batch statistics and BatchNorm's mean corrections).  v_mfma_f32_32x32x2_f32 = an fp32 fmaf chain at the fp32
-// vector peak without any VALU work.  "TN" form, both operands k-major so that every load is a coalesced row piece:
-//     C[m][n] = sum_k sa[k] * A[k][m] * B[k][n]          A [K][lda] (fp32 or bf16), B [K][ldb] bf16, sa optional [K]
-// One workgroup = one 32 x 32 output tile; its 4 waves split K four ways (k = 8*(4*it + wave) + ...) and are summed through LDS in a
-// fixed order: no split-K slabs, 256 tiles x 4 waves fill the chip at w = 512.  Lane (i = lane & 31, h = lane >> 5) feeds MFMA t of an
-// 8-deep k-step with k = k8 + 2t + h (any k order works as long as A and B agree).
+// vector peak without any VALU work.  "NT" form, both operands with k CONTIGUOUS, so that a lane's share of a 16-deep k-step is one
+// 16-byte load per operand (8 bf16; two loads for 8 fp32):
+//     C[m][n] = sum_k sa[k] * A[m][k] * B[n][k]          A [M][lda] (fp32 or bf16), B [N][ldb] bf16, sa optional [K]
+// (the first form read both operands k-major, "TN": one 2- or 4-byte load per lane and k, 32 lanes to a row -- two cache lines per wave
+//  instruction with 64-128 useful bytes; at w = 512 either product took 36-39 us for 1.07 GFLOP, bound by the rate of those line requests.)
+// One workgroup = one 32 x 32 output tile; its 4 waves split K four ways (k = 16*(4*it + wave) + ...) and are summed through LDS in a
+// fixed order: no split-K slabs, 256 tiles x 4 waves fill the chip at w = 512.  Lane (i = lane & 31, h = lane >> 5) feeds MFMA t of a
+// 16-deep k-step with k = k16 + 8h + t (any k order works as long as A and B agree).
 // Epilogues: C as fp32 [M][ldc]; or bf16 of -C; optionally dot[m-tile][n] = sum_{m in tile} C[m][n] * B2[m][n] (the quadratic form
-// w_c G w_c^T per output channel) and vsum[n] = sum_k v[k] B[k][n] on the m-tile-0 workgroups (W^T Kc).
+// w_c G w_c^T per output channel; B2 = B^T, [M][ldb2], read along n) and vsum[n] = sum_k v[k] B[n][k] on the m-tile-0 workgroups (W^T Kc).
 // ------------------------------------------------------------------------------------------------
+constexpr int BL_SAV_MAX = 2048;         // longest K whose sa / v vectors the deep-prefetch instantiations stage in LDS
 // FIN (the forward's product): the LAST workgroup of a column block to arrive (one device-scope counter per block of 32 channels, the arrival
 // pattern of reduce_finish.h: sc1 stores of the partials, every wave's vmcnt(0), barrier, one relaxed atomic) sums the column block's quadratic-
 // form partials over the m tiles in a fixed order, forms mean[c] = W^T[.,c] . m2 / P and finishes scale / shift / mean / invstd (+ running
@@ -56,9 +60,10 @@ __device__ __forceinline__ float ld_f(const uint16_t* p) { return bf16_bits_to_f
 struct BnlinFin {
     const float* m2; double count; const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps;
     float *scale, *shift, *mean_out, *invstd_out; unsigned int* ctr; int w;
+    double* mu_part;          // [w/32][C]: per-tile shares of W^T m2, behind the quadratic-form partials in the `dot` scratch
 };
-template <class TA, bool HAS_SA, bool HAS_V, bool FIN = false>
-__global__ __launch_bounds__(256) void bnlin_tn_gemm_kernel(const TA* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, const float* __restrict__ sa,
+template <class TA, bool HAS_SA, bool HAS_V, bool FIN = false, int D = 1, bool TN = false>
+__global__ __launch_bounds__(256) void bnlin_nt_gemm_kernel(const TA* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, const float* __restrict__ sa,
                                                              int K, float* __restrict__ Cf, uint16_t* __restrict__ Cneg, int ldc,
                                                              const uint16_t* __restrict__ B2, int ldb2, float* __restrict__ dot, int ldd,
                                                              const float* __restrict__ v, float* __restrict__ vsum, BnlinFin fin = BnlinFin{}) {
@@ -71,41 +76,107 @@ __global__ __launch_bounds__(256) void bnlin_tn_gemm_kernel(const TA* __restrict
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float vs = 0.f;
     const bool do_v = HAS_V && blockIdx.y == 0;
-    const TA* ap = A + m0 + i;
-    const uint16_t* bp = B + n0 + i;
-    // K is a multiple of 32: every wave runs K / 32 steps of 8 k.  Two steps of loads (16 values) are in flight ahead of the MFMAs.
-    struct Step { float a[4], b[4], s[4], vv[4]; };
-    auto load = [&](int k8, Step& st) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = k8 + 2 * t + h;
-            st.a[t] = ld_f(ap + (size_t)k * lda);
-            st.b[t] = bf16_bits_to_f32(bp[(size_t)k * ldb]);
-            st.s[t] = HAS_SA ? sa[k] : 1.f;
-            st.vv[t] = HAS_V ? v[k] : 0.f;
-        }
-    };
-    auto fma = [&](const Step& st) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float a = HAS_SA ? st.a[t] * st.s[t] : st.a[t];
-            if (HAS_V) vs += st.vv[t] * st.b[t];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st.b[t], acc, 0, 0, 0);
-        }
-    };
-    Step s0, s1;
-    int k8 = wave * 8;
-    load(k8, s0);
-    if (k8 + 32 < K) load(k8 + 32, s1);
-    for (; k8 + 64 < K; k8 += 64) {
-        Step s2, s3;
-        load(k8 + 64, s2);
-        if (k8 + 96 < K) load(k8 + 96, s3); else s3 = s2;
-        fma(s0); fma(s1);
-        s0 = s2; s1 = s3;
+    const TA* ap = A + (size_t)(m0 + i) * lda + 8 * h;
+    const uint16_t* bp = B + (size_t)(n0 + i) * ldb + 8 * h;
+    // K is a multiple of 16: wave w runs the k-steps 16 (4 it + w).  D steps of loads are in flight ahead of the MFMAs, held as loaded (packed)
+    // registers: one wave's MFMAs are ONE dependent chain (512 cycles per step) and a load takes 1-2 us, so with a single step ahead (and with
+    // the TN form's two) every step waited for its operands -- 36-39 us per product at w = 512 against 7 us of MFMA time.  D > 1 needs
+    // K % (64 D) == 0 and, for sa / v, K <= BL_SAV_MAX: they are staged in LDS once (one address per lane half: broadcast reads).
+    struct Raw { uint4 a0, a1, b; };                    // a1 only for fp32 A
+    __shared__ float lsav[(HAS_SA || HAS_V) && D > 1 ? 2 * BL_SAV_MAX : 1];
+    if constexpr ((HAS_SA || HAS_V) && D > 1) {
+        for (int k = threadIdx.x; k < K; k += 256) { lsav[k] = HAS_SA ? sa[k] : 1.f; lsav[BL_SAV_MAX + k] = HAS_V ? v[k] : 0.f; }
+        __syncthreads();
     }
-    fma(s0);
-    if (k8 + 32 < K) fma(s1);
+    auto unpack8 = [](const uint4 q, float (&o)[8]) {
+        o[0] = bf16_bits_to_f32(q.x & 0xffffu); o[1] = bf16_bits_to_f32(q.x >> 16); o[2] = bf16_bits_to_f32(q.y & 0xffffu); o[3] = bf16_bits_to_f32(q.y >> 16);
+        o[4] = bf16_bits_to_f32(q.z & 0xffffu); o[5] = bf16_bits_to_f32(q.z >> 16); o[6] = bf16_bits_to_f32(q.w & 0xffffu); o[7] = bf16_bits_to_f32(q.w >> 16);
+    };
+    auto load8f = [](const float* p, float (&o)[8]) {
+        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+        o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+    };
+    auto load = [&](int k16, Raw& st) {
+        if constexpr (sizeof(TA) == 4) {
+            st.a0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(ap) + k16);
+            st.a1 = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(ap) + k16 + 4);
+        } else st.a0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(ap) + k16);
+        st.b = *reinterpret_cast<const uint4*>(bp + k16);
+    };
+    auto fma = [&](const Raw& st, int k16) {
+        float a[8], b[8], sc[8], vv[8];
+        if constexpr (sizeof(TA) == 4) {
+            a[0] = __uint_as_float(st.a0.x); a[1] = __uint_as_float(st.a0.y); a[2] = __uint_as_float(st.a0.z); a[3] = __uint_as_float(st.a0.w);
+            a[4] = __uint_as_float(st.a1.x); a[5] = __uint_as_float(st.a1.y); a[6] = __uint_as_float(st.a1.z); a[7] = __uint_as_float(st.a1.w);
+        } else unpack8(st.a0, a);
+        unpack8(st.b, b);
+        if constexpr (HAS_SA) load8f((D > 1 ? lsav : sa) + k16 + 8 * h, sc);
+        if constexpr (HAS_V) load8f((D > 1 ? lsav + BL_SAV_MAX : v) + k16 + 8 * h, vv);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float av = HAS_SA ? a[t] * sc[t] : a[t];
+            if (HAS_V) vs += vv[t] * b[t];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[t], acc, 0, 0, 0);
+        }
+    };
+    int k16 = wave * 16;
+    if constexpr (TN) {
+        // "TN" operands, both k-major (A [K][lda], B [K][ldb]): a lane's share of an 8-deep k-step is 4 + 4 scalar loads (k = k8 + 2t + h), 32 lanes to a
+        // row piece.  Kept for the forward's product G W^T: its A rows are fp32 (2 KB apart at w = 512) and the NT form's 16-byte pieces of 32 different
+        // rows per instruction measured slower there (53 against 36 us at w = 512); D steps in flight as above (K % (32 D) == 0).
+        static_assert(!HAS_SA && !HAS_V, "TN form: plain product only");
+        const TA* apt = A + m0 + i;
+        const uint16_t* bpt = B + n0 + i;
+        struct RawT { float a[4]; uint32_t b[4]; };
+        auto load_t = [&](int k8, RawT& st) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = k8 + 2 * t + h;
+                st.a[t] = ld_f(apt + (size_t)k * lda);
+                st.b[t] = bpt[(size_t)k * ldb];
+            }
+        };
+        auto fma_t = [&](const RawT& st) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(st.a[t], bf16_bits_to_f32(st.b[t]), acc, 0, 0, 0);
+        };
+        int k8 = wave * 8;
+        RawT ring[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_t(k8 + 32 * d, ring[d]);
+        for (; k8 + 32 * D < K; k8 += 32 * D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                fma_t(ring[d]);
+                load_t(k8 + 32 * (D + d), ring[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) fma_t(ring[d]);
+    } else if constexpr (D > 1) {
+        Raw ring[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(k16 + 64 * d, ring[d]);
+        for (; k16 + 64 * D < K; k16 += 64 * D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                fma(ring[d], k16 + 64 * d);
+                load(k16 + 64 * (D + d), ring[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) fma(ring[d], k16 + 64 * d);
+    } else if (k16 < K) {
+        Raw s0;
+        load(k16, s0);
+        for (; k16 + 64 < K; k16 += 64) {
+            Raw s1;
+            load(k16 + 64, s1);
+            fma(s0, k16);
+            s0 = s1;
+        }
+        fma(s0, k16);
+    }
     if (!do_v) vs = 0.f;
     // C/D layout: column n = n0 + i, row m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h
     if (wave > 0) {
@@ -118,15 +189,24 @@ __global__ __launch_bounds__(256) void bnlin_tn_gemm_kernel(const TA* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
         float d = 0.f;
+        double dm = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + i;
             if (Cf) Cf[(size_t)m * ldc + n] = acc[r];
             if (Cneg) Cneg[(size_t)m * ldc + n] = f32_to_bf16_bits(-acc[r]);
-            if (B2) d += acc[r] * bf16_bits_to_f32(B2[(size_t)m * ldb2 + n]);
+            if (B2) {
+                const float b2 = bf16_bits_to_f32(B2[(size_t)m * ldb2 + n]);
+                d += acc[r] * b2;
+                if constexpr (FIN) dm += (double)b2 * (double)fin.m2[m];         // this tile's share of W^T m2 (the channel means), B2 = W^T
+            }
         }
         if (B2) {
             d += __shfl_xor(d, 32, 64);                 // the two row halves of the tile
+            if constexpr (FIN) {
+                dm += __shfl_xor(dm, 32, 64);
+                if (h == 0) __hip_atomic_store(&fin.mu_part[(size_t)blockIdx.y * ldd + n0 + i], dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (h == 0) {
                 if constexpr (FIN) __hip_atomic_store(&dot[(size_t)blockIdx.y * ldd + n0 + i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: seen by the finishing workgroup on any XCD
                 else dot[(size_t)blockIdx.y * ldd + n0 + i] = d;
@@ -152,8 +232,12 @@ __global__ __launch_bounds__(256) void bnlin_tn_gemm_kernel(const TA* __restrict
         if (!s_last) return;
         const int cx = threadIdx.x & 31, grp = threadIdx.x >> 5, c = n0 + cx;      // 32 channels x 8 groups over k / over the m tiles, fixed order
         double mu = 0.0, q = 0.0;
-        for (int k = grp; k < fin.w; k += 8) mu += (double)bf16_bits_to_f32(B[(size_t)k * ldb + c]) * (double)fin.m2[k];
-        for (int t = grp; t < (int)gridDim.y; t += 8) q += (double)__hip_atomic_load(&dot[(size_t)t * ldd + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the means W^T m2 were a loop over k here, 64 dependent rounds of loads at w = 512: 14 of the launch's 36 us; every tile now leaves its share
+        //  beside its quadratic-form partial, from the B2 values its epilogue loads anyway)
+        for (int t = grp; t < (int)gridDim.y; t += 8) {
+            q += (double)__hip_atomic_load(&dot[(size_t)t * ldd + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mu += __hip_atomic_load(&fin.mu_part[(size_t)t * ldd + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         fred[0][grp][cx] = mu; fred[1][grp][cx] = q;
         __syncthreads();
         if (grp == 0) {
@@ -273,25 +357,44 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const uint16_t* __restri
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
-// Wt = W^T [w][C] bf16 (the plain data-gradient image of the convolution); ut [w][C] fp32 and dot [w/32][C] fp32 are outputs the
+// k-steps of loads in flight per wave: as many as K allows (K % (64 D) == 0), at most 8 (DALI_BNLIN_DEPTH caps it: A/B)
+static int bnlin_depth_tn(int K) {         // TN form: 8-deep steps, K % (32 D) == 0; D = 2 is the round-4 kernel
+    const int cap = DALI_ENV_INT("DALI_BNLIN_DEPTH_TN", 4);
+    int d = 1;
+    while (d < 8 && 2 * d <= cap && K % (64 * d) == 0) d *= 2;
+    return d;
+}
+static int bnlin_depth(int K) {
+    const int cap = DALI_ENV_INT("DALI_BNLIN_DEPTH", 8);
+    int d = 1;
+    while (d < 8 && 2 * d <= cap && K % (128 * d) == 0) d *= 2;
+    return d;
+}
+// Wt = W^T [w][C] bf16 (the plain data-gradient image of the convolution); ut [w][C] fp32 and dot ((w/32) * C * 12 bytes: per-tile fp32 quadratic-form and fp64 mean partials) are outputs the
 // backward / the finish kernel read
-int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
+int launch_bnlin_stats(hipStream_t st, const uint16_t* W, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
                        const float* beta, float* rm, float* rv, float momentum, float eps, float* ut, float* dot, float* scale, float* shift,
                        float* mean, float* invstd) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
-    // Ut[k'][c] = sum_k G[k][k'] Wt[k][c]  (G symmetric: read as A[k][m = k']); dot[tile][c] = sum_{k' in tile} Ut[k'][c] Wt[k'][c]
+    // Ut[k'][c] = sum_k G[k'][k] W[c][k]  (G symmetric); dot[tile][c] = sum_{k' in tile} Ut[k'][c] Wt[k'][c]
     if (C / 32 <= RF_GROUPS && DALI_ENV_INT("DALI_BNLIN_FUSED_FINISH", 1) != 0) {
         // the statistics finish in the product's own launch, by the last workgroup of every 32-channel column block (see BnlinFin)
         unsigned int* ctr = nullptr;
         if (int rc = rf_counter_base(&ctr)) return rc;
         ctr += (size_t)rf_next_slot() * RF_GROUPS;
-        const BnlinFin fin{m2, count, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd, ctr, w};
-        hipLaunchKernelGGL((bnlin_tn_gemm_kernel<float, false, false, true>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, Wt, C, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
-                           Wt, C, dot, C, (const float*)nullptr, (float*)nullptr, fin);
+        const BnlinFin fin{m2, count, gamma, beta, rm, rv, momentum, eps, scale, shift, mean, invstd, ctr, w, reinterpret_cast<double*>(dot + (size_t)(w / 32) * C)};
+#define BL_FWD_FIN(DEPTH, TNF) hipLaunchKernelGGL((bnlin_nt_gemm_kernel<float, false, false, true, DEPTH, TNF>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, TNF ? Wt : W, TNF ? C : w, \
+                                                  (const float*)nullptr, w, ut, (uint16_t*)nullptr, C, Wt, C, dot, C, (const float*)nullptr, (float*)nullptr, fin)
+        if (DALI_ENV_INT("DALI_BNLIN_FWD_NT", 0)) {
+            switch (bnlin_depth(w)) { case 8: BL_FWD_FIN(8, false); break; case 4: BL_FWD_FIN(4, false); break; case 2: BL_FWD_FIN(2, false); break; default: BL_FWD_FIN(1, false); }
+        } else {
+            switch (bnlin_depth_tn(w)) { case 8: BL_FWD_FIN(8, true); break; case 4: BL_FWD_FIN(4, true); break; case 2: BL_FWD_FIN(2, true); break; default: BL_FWD_FIN(1, true); }
+        }
+#undef BL_FWD_FIN
         DALI_LAUNCH_CHECK();
         return DALI_OK;
     }
-    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<float, false, false>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, Wt, C, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
+    hipLaunchKernelGGL((bnlin_nt_gemm_kernel<float, false, false>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, W, w, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
                        Wt, C, dot, C, (const float*)nullptr, (float*)nullptr);
     DALI_LAUNCH_CHECK();
     hipLaunchKernelGGL(bnlin_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, st, dot, w / 32, Wt, m2, C, w, count, gamma, beta, rm, rv, momentum, eps,
@@ -301,15 +404,15 @@ int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, co
 }
 
 // only Ut = (W G)^T [w][C] (a scheme whose forward statistics come from elsewhere: the downsample branch, resnet_plan.hip)
-int launch_bnlin_ut(hipStream_t st, const uint16_t* Wt, const float* gram, int C, int w, float* ut) {
+int launch_bnlin_ut(hipStream_t st, const uint16_t* W, const float* gram, int C, int w, float* ut) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
-    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<float, false, false>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, Wt, C, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
+    hipLaunchKernelGGL((bnlin_nt_gemm_kernel<float, false, false>), dim3(C / 32, w / 32), dim3(256), 0, st, gram, w, W, w, (const float*)nullptr, w, ut, (uint16_t*)nullptr, C,
                        (const uint16_t*)nullptr, 0, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
 
-int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
+int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const uint16_t* Wt, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk, int ld1, int ld2) {
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
@@ -318,9 +421,11 @@ int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const f
     hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, W, ut, m2, s_dz, C, w,
                        count, scale, mean, invstd, dW, dgamma, dbeta, wd1, ld1, qk);
     DALI_LAUNCH_CHECK();
-    // wd2 = -(W^T diag(Q) W) [w][w] (bf16), bvec = W^T Kc: A = B = W [K = C][w], scaled by Q along K; v = Kc
-    hipLaunchKernelGGL((bnlin_tn_gemm_kernel<uint16_t, true, true>), dim3(w / 32, w / 32), dim3(256), 0, st, W, w, W, w, qk, C, (float*)nullptr, wd2, ld2,
-                       (const uint16_t*)nullptr, 0, (float*)nullptr, 0, qk + C, bvec);
+    // wd2 = -(W^T diag(Q) W) [w][w] (bf16), bvec = W^T Kc: A = B = Wt [w][K = C], scaled by Q along K; v = Kc
+#define BL_BWD(DEPTH) hipLaunchKernelGGL((bnlin_nt_gemm_kernel<uint16_t, true, true, false, DEPTH>), dim3(w / 32, w / 32), dim3(256), 0, st, Wt, C, Wt, C, qk, C, (float*)nullptr, wd2, ld2, \
+                                         (const uint16_t*)nullptr, 0, (float*)nullptr, 0, qk + C, bvec)
+    switch (C <= BL_SAV_MAX ? bnlin_depth(C) : 1) { case 8: BL_BWD(8); break; case 4: BL_BWD(4); break; case 2: BL_BWD(2); break; default: BL_BWD(1); }
+#undef BL_BWD
     DALI_LAUNCH_CHECK();
     return DALI_OK;
 }
@@ -350,7 +455,7 @@ extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, co
     const bool fused_cs = wgrad_colsum_supported(w, w, 1, P);
     const int cs_rows = wgrad_colsum_rows(w, w, 1, P, wa.splits);             // one row per split, or per (split, n tile) from the 128 x 256 kernels
     const size_t b_cs = align_up(std::max(colsum_partial_floats(P, w), (size_t)cs_rows * w) * 4, 256), b_sc = align_up(reduce_scratch_bytes(w, 1), 256);
-    const size_t b_wt = align_up((size_t)C * w * 2, 256), b_dot = align_up((size_t)(w / 32) * C * 4, 256);
+    const size_t b_wt = align_up((size_t)C * w * 2, 256), b_dot = align_up((size_t)(w / 32) * C * 12, 256);      // quadratic-form partials (fp32) + mean partials (fp64)
     char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + b_wt + b_dot));
     if (!ws) return DALI_ERR_NOMEM;
     wa.partial = reinterpret_cast<float*>(ws);
@@ -364,7 +469,7 @@ extern "C" int dali_bnlin_fwd(dali_ctx* ctx, void* stream, const uint16_t* a, co
     if ((rc = launch_igemm_wgrad(st, wa, gram, 0, fused_cs ? m2 : nullptr, cs_rows))) return rc;
     if (!fused_cs && (rc = launch_colsum(st, a, P, w, m2, cs_partial, scratch))) return rc;
     if ((rc = launch_weight_transpose(st, W, C, 1, w, wt))) return rc;
-    return launch_bnlin_stats(st, wt, gram, m2, C, w, (double)P, gamma, beta, running_mean, running_var, momentum, eps, ut, dot, scale, shift, mean, invstd);
+    return launch_bnlin_stats(st, W, wt, gram, m2, C, w, (double)P, gamma, beta, running_mean, running_var, momentum, eps, ut, dot, scale, shift, mean, invstd);
 }
 
 extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, const uint16_t* a, const uint16_t* W, int P, int C, int w,
@@ -380,18 +485,20 @@ extern "C" int dali_bnlin_bwd(dali_ctx* ctx, void* stream, const uint16_t* dz, c
     const bool fused_cs = wgrad_colsum_supported(C, w, 1, P);
     const int cs_rows = wgrad_colsum_rows(C, w, 1, P, wa.splits);
     const size_t b_cs = align_up(std::max(colsum_partial_floats(P, C), (size_t)cs_rows * C) * 4, 256), b_sc = align_up(reduce_scratch_bytes(C, 1), 256);
-    const size_t b_v = align_up((size_t)C * 4, 256);
-    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + 3 * b_v));
+    const size_t b_v = align_up((size_t)C * 4, 256), b_wt = align_up((size_t)C * w * 2, 256);
+    char* ws = static_cast<char*>(workspace(ctx, align_up(wsb, 256) + b_cs + b_sc + 3 * b_v + b_wt));
     if (!ws) return DALI_ERR_NOMEM;
     wa.partial = reinterpret_cast<float*>(ws);
     char* p = ws + align_up(wsb, 256);
     float* cs_partial = reinterpret_cast<float*>(p); p += b_cs;
     double* scratch = reinterpret_cast<double*>(p); p += b_sc;
     float* sdz = reinterpret_cast<float*>(p); p += b_v;
-    float* qk = reinterpret_cast<float*>(p);
+    float* qk = reinterpret_cast<float*>(p); p += 2 * b_v;
+    uint16_t* wt = reinterpret_cast<uint16_t*>(p);
     int rc;
     if (fused_cs) wa.colsum = cs_partial;
+    if ((rc = launch_weight_transpose(st, W, C, 1, w, wt))) return rc;
     if ((rc = launch_igemm_wgrad(st, wa, dW, 0, fused_cs ? sdz : nullptr, cs_rows))) return rc;                       // G0 -> dW
     if (!fused_cs && (rc = launch_colsum(st, dz, P, C, sdz, cs_partial, scratch))) return rc;
-    return launch_bnlin_bwd(st, W, ut, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
+    return launch_bnlin_bwd(st, W, wt, ut, m2, sdz, C, w, (double)P, scale, mean, invstd, dW, dgamma, dbeta, wd1, wd2, bvec, qk);
 }

@@ -112,17 +112,17 @@ int wgrad_colsum_rows(int Cm, int Ntot, int taps, int P, int splits);
 size_t linear_wgrad_slab_bytes(int rows, int K, int N);
 
 // bnlin.hip: BatchNorm behind a 1x1 convolution from the moments of the convolution's INPUT (no raw conv output is stored)
-//   forward : scale / shift / mean / invstd of raw = a W^T from gram = a^T a [w][w] and m2 = colsum(a) [w]; Wt = W^T bf16 [w][C];
-//             leaves ut = (W gram)^T [w][C] for the backward, dot [w/32][C] is scratch
+//   forward : scale / shift / mean / invstd of raw = a W^T from gram = a^T a [w][w] and m2 = colsum(a) [w]; W [C][w] and Wt = W^T [w][C] bf16;
+//             leaves ut = (W gram)^T [w][C] for the backward, dot is scratch of (w/32) * C * 12 bytes (fp32 quadratic-form + fp64 mean partials per 32-row tile)
 //   backward: split-K slabs of G0 = dz^T a (+ s_dz = colsum(dz)) -> dW [C][w], dgamma, dbeta, and the two data-gradient weight images
 //             wd1 = (A.W)^T [w][C], wd2 = -(W^T diag(Q) W) [w][w] with bvec = W^T Kc [w]; qk [2][C] is scratch
-int launch_bnlin_stats(hipStream_t st, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
+int launch_bnlin_stats(hipStream_t st, const uint16_t* W, const uint16_t* Wt, const float* gram, const float* m2, int C, int w, double count, const float* gamma,
                        const float* beta, float* rm, float* rv, float momentum, float eps, float* ut, float* dot, float* scale, float* shift,
                        float* mean, float* invstd);
 // dW holds G0 = dz^T a (the reduced weight-gradient GEMM) on entry and the weight gradient on return; s_dz = colsum(dz) [C]
 // ld1 / ld2: row pitch (elements) of wd1 / wd2 (the net plan writes both into one [w][C + w] image: ld1 = ld2 = C + w, wd2 = wd1 + C)
-int launch_bnlin_ut(hipStream_t st, const uint16_t* Wt, const float* gram, int C, int w, float* ut);
-int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const float* ut, const float* m2, const float* s_dz, int C,
+int launch_bnlin_ut(hipStream_t st, const uint16_t* W, const float* gram, int C, int w, float* ut);
+int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const uint16_t* Wt, const float* ut, const float* m2, const float* s_dz, int C,
                      int w, double count, const float* scale, const float* mean, const float* invstd, float* dW, float* dgamma, float* dbeta,
                      uint16_t* wd1, uint16_t* wd2, float* bvec, float* qk, int ld1 = 0, int ld2 = 0);
 

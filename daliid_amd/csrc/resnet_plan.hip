@@ -270,7 +270,7 @@ extern "C" int dali_resnet_create(dali_ctx* ctx, const dali_resnet_cfg* cfg, dal
             reserve(net, a, b.gram, (size_t)b.width * b.width * 4); reserve(net, a, b.m2, (size_t)b.width * 4);
             reserve(net, a, b.sdz, (size_t)b.cout * 4); reserve(net, a, b.bvec, (size_t)b.width * 4); reserve(net, a, b.qk, (size_t)b.cout * 8);
             reserve(net, a, b.wd1, (size_t)b.width * (b.cout + b.width) * 2);          // [w][cout + w]: (A.W3)^T | -(W3^T diag(Q) W3), one data-gradient image
-            reserve(net, a, b.ut, (size_t)b.width * b.cout * 4); reserve(net, a, b.dot, (size_t)(b.width / 32) * b.cout * 4);
+            reserve(net, a, b.ut, (size_t)b.width * b.cout * 4); reserve(net, a, b.dot, (size_t)(b.width / 32) * b.cout * 12);
             max_cs = std::max(max_cs, std::max(colsum_partial_floats((int)pout, b.cout), colsum_partial_floats((int)pout, b.width)) * 4);
             int sp, pps; size_t wsb;
             wgrad_plan(b.width, b.width, (int)pout, 512, &sp, &pps, &wsb, 1, 0);
@@ -531,7 +531,7 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                 if (fused_cs) wa.colsum = net->cs_partial;
                 if ((rc = launch_igemm_wgrad(st, wa, b.gram, 0, fused_cs ? b.m2 : nullptr, fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;
                 if (!fused_cs && (rc = launch_colsum(st, b.a2, Pout, b.width, b.m2, net->cs_partial, net->red_scratch))) return rc;
-                if ((rc = launch_bnlin_stats(st, b.c3.wt_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
+                if ((rc = launch_bnlin_stats(st, b.c3.w_bf16, b.c3.wt_bf16, b.gram, b.m2, b.cout, b.width, (double)Pout, net->P + b.b3.g_off, net->P + b.b3.b_off,
                                              net->B + b.b3.rm_off, net->B + b.b3.rv_off, 0.1f, 1e-5f, b.ut, b.dot, b.b3.scale, b.b3.shift, b.b3.mean,
                                              b.b3.invstd))) return rc;
             }
@@ -567,7 +567,7 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
                     if (fused_cs) wa.colsum = net->cs_partial;
                     if ((rc = launch_igemm_wgrad(st, wa, b.gram_d, 0, fused_cs ? b.m2_d : nullptr, fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;
                     if (!fused_cs && (rc = launch_colsum(st, x, Pout, b.cin, b.m2_d, net->cs_partial, net->red_scratch))) return rc;
-                    if ((rc = launch_bnlin_ut(st, b.cd.wt_bf16, b.gram_d, b.cout, b.cin, b.ut_d))) return rc;
+                    if ((rc = launch_bnlin_ut(st, b.cd.w_bf16, b.gram_d, b.cout, b.cin, b.ut_d))) return rc;
                 }
             }
             a.bits_out = tr ? b.ybits : nullptr;
@@ -613,7 +613,7 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
                                      fused_cs ? wgrad_colsum_rows(wa.Cm, wa.Ntot, 1, wa.P, wa.splits) : 0))) return rc;           // G0 = dz^T a2 into the gradient slot; finished in place below
         if (!fused_cs && (rc = launch_colsum(st, dz, Pout, b.cout, b.sdz, net->cs_partial, net->red_scratch))) return rc;
         const int ldw = b.cout + b.width;
-        if ((rc = launch_bnlin_bwd(st, b.c3.w_bf16, b.ut, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
+        if ((rc = launch_bnlin_bwd(st, b.c3.w_bf16, b.c3.wt_bf16, b.ut, b.m2, b.sdz, b.cout, b.width, (double)Pout, b.b3.scale, b.b3.mean,
                                    b.b3.invstd, net->G + b.c3.w_off, net->G + b.b3.g_off, net->G + b.b3.b_off, b.wd1, b.wd1 + b.cout, b.bvec, b.qk, ldw, ldw))) return rc;
         d_a2 = next_gbuf(net, dz);
         scratch_a = next_gbuf(net, dz, d_a2);
@@ -637,7 +637,7 @@ static int block_backward(dali_resnet* net, hipStream_t st, Block& b, const uint
             wgrad_plan(wd.Cm, wd.Ntot, wd.P, 512, &wd.splits, &wd.pix_per_split, &wsb2, 1, 0);
             if ((rc = launch_igemm_wgrad(st, wd, net->G + b.cd.w_off, 0))) return rc;
             const int ldd = b.cout + b.cin;
-            if ((rc = launch_bnlin_bwd(st, b.cd.w_bf16, b.ut_d, b.m2_d, b.sdz, b.cout, b.cin, (double)Pout, b.bd.scale, b.bd.mean, b.bd.invstd,
+            if ((rc = launch_bnlin_bwd(st, b.cd.w_bf16, b.cd.wt_bf16, b.ut_d, b.m2_d, b.sdz, b.cout, b.cin, (double)Pout, b.bd.scale, b.bd.mean, b.bd.invstd,
                                        net->G + b.cd.w_off, net->G + b.bd.g_off, net->G + b.bd.b_off, b.wdd, b.wdd + b.cout, b.bvec_d, b.qk_d, ldd, ldd))) return rc;
         } else if (b.has_ds) {                                    // the downsample BatchNorm: its own two passes over (dz, rawd)
             d_rawd = next_gbuf(net, dz, d_a2, scratch_a);
