@@ -318,23 +318,53 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const uint16_t* __restri
     extern __shared__ __attribute__((aligned(16))) float bl_smem[];
     float* wf = bl_smem;                                    // [BL_CH][w]
     float* g0 = wf + BL_CH * w;                             // [BL_CH][w]
-    __shared__ double red[4];
+    float* us = g0 + BL_CH * w;                             // [w][BL_CH]: this group's columns of Ut
+    float* m2s = us + BL_CH * w;                            // [w]
+    __shared__ double red[4][BL_CH];
     __shared__ float coef[BL_CH][4];                        // A, Kc, Q, pad
     const int c0 = blockIdx.x * BL_CH;                      // C % BL_CH == 0 (checked by the launcher)
-    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {
-        g0[e] = dW[(size_t)c0 * w + e];
-        wf[e] = bf16_bits_to_f32(W[(size_t)c0 * w + e]);
+    // Every global read of the kernel is requested here, in whole 16-byte pieces and unrolled (the first form's element loops had run-time trip
+    // counts: one load round trip per iteration, 16 + 16 of them at w = 512 -- 12 us per launch for 50 KB of data).  The 8 rows of G0 and of W are
+    // contiguous; Ut's 8 columns are 32-byte pieces of its rows.  w % 32 == 0.
+    {
+        const float4* gsrc = reinterpret_cast<const float4*>(dW + (size_t)c0 * w);
+        const uint4* wsrc = reinterpret_cast<const uint4*>(W + (size_t)c0 * w);
+        const int n4 = BL_CH * w / 4, n8 = BL_CH * w / 8;
+#pragma unroll 4
+        for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(g0)[e] = gsrc[e];
+#pragma unroll 2
+        for (int e = threadIdx.x; e < n8; e += 256) {
+            const uint4 q = wsrc[e];
+            float4 lo, hi;
+            lo.x = bf16_bits_to_f32(q.x & 0xffffu); lo.y = bf16_bits_to_f32(q.x >> 16); lo.z = bf16_bits_to_f32(q.y & 0xffffu); lo.w = bf16_bits_to_f32(q.y >> 16);
+            hi.x = bf16_bits_to_f32(q.z & 0xffffu); hi.y = bf16_bits_to_f32(q.z >> 16); hi.z = bf16_bits_to_f32(q.w & 0xffffu); hi.w = bf16_bits_to_f32(q.w >> 16);
+            reinterpret_cast<float4*>(wf)[2 * e] = lo; reinterpret_cast<float4*>(wf)[2 * e + 1] = hi;
+        }
+#pragma unroll 4
+        for (int e = threadIdx.x; e < 2 * w; e += 256)      // float4 e: row k = e >> 1, half e & 1 of its 8 columns
+            reinterpret_cast<float4*>(us)[e] = *reinterpret_cast<const float4*>(Ut + (size_t)(e >> 1) * C + c0 + 4 * (e & 1));
+        for (int e = threadIdx.x; e < w / 4; e += 256) reinterpret_cast<float4*>(m2s)[e] = reinterpret_cast<const float4*>(m2)[e];
     }
     __syncthreads();
+    {   // T[ch] = sum_p dz * raw3 = rowdot(W, G0): the 8 channels' partial sums per thread, ONE reduction (8 block reductions in a row before)
+        double t[BL_CH];
 #pragma unroll
-    for (int ch = 0; ch < BL_CH; ++ch) {                    // T = sum_p dz * raw3 = rowdot(W, G0)
-        double t = 0.0;
-        for (int k = threadIdx.x; k < w; k += 256) t += (double)wf[ch * w + k] * (double)g0[ch * w + k];
-        t = block_sum_d(t, red);
-        const int c = c0 + ch;
-        if (threadIdx.x == 0) {
+        for (int ch = 0; ch < BL_CH; ++ch) {
+            t[ch] = 0.0;
+            for (int k = threadIdx.x; k < w; k += 256) t[ch] += (double)wf[ch * w + k] * (double)g0[ch * w + k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t[ch] += __shfl_xor(t[ch], o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int ch = 0; ch < BL_CH; ++ch) red[threadIdx.x >> 6][ch] = t[ch];
+        }
+        __syncthreads();
+        if (threadIdx.x < BL_CH) {
+            const int ch = threadIdx.x, c = c0 + ch;
+            const double tt = (red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch]);
             const double s = (double)s_dz[c], iv = (double)invstd[c], mn = (double)mean[c], a = (double)scale[c];
-            const double dg = iv * (t - mn * s);                    // sum dz * xhat
+            const double dg = iv * (tt - mn * s);                   // sum dz * xhat
             const double qq = a * iv * dg / count;
             dgamma[c] = (float)dg;
             dbeta[c] = (float)s;
@@ -343,10 +373,9 @@ __global__ __launch_bounds__(256) void bnlin_row_kernel(const uint16_t* __restri
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // dW[c][k] = A G0 + Kc m2 - Q (W G)   (thread -> (k, ch): 32-byte pieces of Ut rows)
-        const int k = e / BL_CH, ch = e - k * BL_CH;
-        const float u = Ut[(size_t)k * C + c0 + ch];
-        dW[(size_t)(c0 + ch) * w + k] = coef[ch][0] * g0[ch * w + k] + coef[ch][1] * m2[k] - coef[ch][2] * u;
+    for (int e = threadIdx.x; e < BL_CH * w; e += 256) {    // dW[c][k] = A G0 + Kc m2 - Q (W G)   (k fastest: whole rows of dW per channel)
+        const int ch = e / w, k = e - ch * w;
+        dW[(size_t)(c0 + ch) * w + k] = coef[ch][0] * g0[e] + coef[ch][1] * m2s[k] - coef[ch][2] * us[k * BL_CH + ch];
     }
     for (int k = threadIdx.x; k < w; k += 256) {            // A.W, transposed into the data-gradient image [w][C]: 8 channels = 16 bytes per k
         uint32_t o[4];
@@ -418,7 +447,8 @@ int launch_bnlin_bwd(hipStream_t st, const uint16_t* W, const uint16_t* Wt, cons
     if (w % 32 != 0 || C % 32 != 0) { set_error("bnlin: width %d and channels %d must be multiples of 32", w, C); return DALI_ERR_INVALID; }
     if (ld1 <= 0) ld1 = C;
     if (ld2 <= 0) ld2 = w;
-    hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)2 * BL_CH * w * sizeof(float), st, W, ut, m2, s_dz, C, w,
+    if ((size_t)(3 * BL_CH + 1) * w * sizeof(float) > 64 * 1024) { set_error("bnlin: width %d: the row kernel keeps 25 w floats in LDS (w <= 640)", w); return DALI_ERR_LIMIT; }
+    hipLaunchKernelGGL(bnlin_row_kernel, dim3(C / BL_CH), dim3(256), (size_t)(3 * BL_CH + 1) * w * sizeof(float), st, W, ut, m2, s_dz, C, w,
                        count, scale, mean, invstd, dW, dgamma, dbeta, wd1, ld1, qk);
     DALI_LAUNCH_CHECK();
     // wd2 = -(W^T diag(Q) W) [w][w] (bf16), bvec = W^T Kc: A = B = Wt [w][K = C], scaled by Q along K; v = Kc

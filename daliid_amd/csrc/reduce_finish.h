@@ -67,7 +67,14 @@ __global__ __launch_bounds__(256) void reduce_finish_kernel(const float* __restr
         const double* p = scratch + col;                 // device-scope (sc1) loads: the other blocks' rows, not a stale line of this XCD's L2
         double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int t = 0;
-        for (; t + 16 <= S; t += 16) {                   // 16 loads in flight: S = 64 rows are four round trips
+        for (; t + 32 <= S; t += 32) {                   // 32 loads in flight: S = 64 rows are two round trips (same slice order as below)
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = __hip_atomic_load(p + (size_t)(t + u) * cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) a[u & 7] += v[u];
+        }
+        for (; t + 16 <= S; t += 16) {
             double v[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) v[u] = __hip_atomic_load(p + (size_t)(t + u) * cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
