@@ -967,6 +967,94 @@ extern "C" int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const void* q
                            metric, precision == DALI_PREC_BF16X3, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small similarity GEMMs (the loss heads' fn @ centers^T, fn @ proxies^T, dS @ centers: 256 x 751 .. 2253 x 2048, losses.py:62, :277) on the fp32
+// MFMA: out[m][n] = sum_k Q[m][k] G[n][k], exact fp32 products, no operand pre-pass.  The persistent distance kernel gives a 128 x 256 tile
+// to one CU: 6-18 of the 256 CUs worked on these, 46 us per launch + two 8 us operand pre-passes.  Here: one workgroup per 32 x 32 tile
+// (192-568 workgroups), its 4 waves split K in 16-deep steps (lane (i, h) takes k = k16 + 8h + t: two 16-byte loads per operand), D steps of
+// loads in flight ahead of each wave's MFMA chain, partial tiles summed through LDS in a fixed order.  Rows past nq / ng are clamped onto the
+// last row and masked at the store; k-steps past a wave's share are clamped and multiplied by zero; the K % 16 tail is one masked step.
+// ------------------------------------------------------------------------------------------------
+namespace dali {
+template <int D>
+__global__ __launch_bounds__(256) void dot_small_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ G, int ldg, int nq, int ng, int K,
+                                                        float* __restrict__ out, int ldo) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const float* ap = Q + (size_t)min(m0 + i, nq - 1) * ldq + 8 * h;
+    const float* bp = G + (size_t)min(n0 + i, ng - 1) * ldg + 8 * h;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nfull = K >> 4;                              // whole 16-deep steps; wave w takes steps w, w + 4, ...
+    const int ns = (nfull + 3) >> 2;                       // turns per wave (the last may be past a wave's share: clamped, weight 0)
+    struct Raw { float4 a0, a1, b0, b1; };
+    auto load = [&](int j, Raw& st) {
+        const int sc = min(wave + 4 * j, nfull - 1);
+        st.a0 = *reinterpret_cast<const float4*>(ap + 16 * sc); st.a1 = *reinterpret_cast<const float4*>(ap + 16 * sc + 4);
+        st.b0 = *reinterpret_cast<const float4*>(bp + 16 * sc); st.b1 = *reinterpret_cast<const float4*>(bp + 16 * sc + 4);
+    };
+    auto fma = [&](const Raw& st, int j) {
+        const float z = wave + 4 * j < nfull ? 1.f : 0.f;
+        const float a[8] = {st.a0.x * z, st.a0.y * z, st.a0.z * z, st.a0.w * z, st.a1.x * z, st.a1.y * z, st.a1.z * z, st.a1.w * z};
+        const float b[8] = {st.b0.x, st.b0.y, st.b0.z, st.b0.w, st.b1.x, st.b1.y, st.b1.z, st.b1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    };
+    if (nfull > 0) {
+        Raw ring[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(d, ring[d]);
+        for (int j0 = 0; j0 < ns; j0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                fma(ring[d], j0 + d);
+                load(j0 + d + D, ring[d]);
+            }
+        }
+    }
+    if ((K & 15) && wave == 0) {                           // the ragged end of K: one masked step
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int k = 16 * nfull + 8 * h + t;          // (ap / bp already carry the 8h)
+            const float a = k < K ? ap[16 * nfull + t] : 0.f, b = k < K ? bp[16 * nfull + t] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int n = n0 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+            if (m < nq && n < ng) out[(size_t)m * ldo + n] = v;
+        }
+    }
+}
+// does dali_pairdist take this problem on the small kernel?  plain dot products at fp32 grade whose 128 x 256 tiles would occupy at most a
+// quarter of the CUs (DALI_PAIRDIST_SMALL=0: always the persistent kernel, for A/B)
+static bool dot_small_applies(int num_cus, int nq, int ng, int d, int metric, int precision, int normalize) {
+    if (metric != DALI_METRIC_DOT || normalize || precision != DALI_PREC_BF16X3 || d < 16) return false;
+    const long long big_tiles = (long long)((nq + 127) / 128) * ((ng + 255) / 256);
+    return big_tiles * 4 <= num_cus && DALI_ENV_INT("DALI_PAIRDIST_SMALL", 1) != 0;
+}
+static int launch_dot_small(hipStream_t st, const float* Q, const float* G, int nq, int ng, int d, float* out) {
+    const dim3 grid((ng + 31) / 32, (nq + 31) / 32);
+    const int turns = ((d >> 4) + 3) >> 2;
+    if (turns >= 8) hipLaunchKernelGGL(dot_small_kernel<8>, grid, dim3(256), 0, st, Q, d, G, d, nq, ng, d, out, ng);
+    else if (turns >= 4) hipLaunchKernelGGL(dot_small_kernel<4>, grid, dim3(256), 0, st, Q, d, G, d, nq, ng, d, out, ng);
+    else hipLaunchKernelGGL(dot_small_kernel<2>, grid, dim3(256), 0, st, Q, d, G, d, nq, ng, d, out, ng);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
+}  // namespace dali
+
 // gallery image, query image and the squared norms in the context workspace
 static int prepare_both(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d, int precision, int normalize,
                         uint16_t*& g_img, uint16_t*& q_img, float*& sq) {
@@ -990,6 +1078,7 @@ extern "C" int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const 
     DALI_REQUIRE(precision == DALI_PREC_BF16X3 || precision == DALI_PREC_BF16, "dali_pairdist: bad precision %d", precision);
     DALI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dali_pairdist: out must be 16-byte aligned");
     if (nq == 0 || ng == 0) return DALI_OK;
+    if (dot_small_applies(ctx->num_cus, nq, ng, d, metric, precision, normalize)) return launch_dot_small((hipStream_t)stream, Q, G, nq, ng, d, out);
     uint16_t *g_img, *q_img;
     float* sq;
     const int rc = prepare_both(ctx, stream, Q, G, nq, ng, d, precision, normalize, g_img, q_img, sq);

@@ -72,6 +72,39 @@ def test_pairdist_matches_oracle(ops, prec, atol, nq, ng, d):
     assert rel <= (8e-6 if prec == "bf16x3" else 8e-3)
 
 
+@pytest.mark.parametrize("nq,ng,d", [(256, 751, 2048), (256, 2253, 2048), (256, 2048, 751), (1, 5, 16), (33, 65, 40), (70, 31, 23), (384, 751, 768), (5, 3, 7)])
+def test_dot_similarities_of_the_loss_heads_exact_and_on_either_kernel(ops, nq, ng, d):
+    """metric="dot" (the heads' fn @ centers^T, fn @ proxies^T, dS @ centers: losses.py:62, :277).  Problems whose 128 x 256 tiles would
+    occupy at most a quarter of the CUs leave through the small fp32-MFMA kernel (dot_small_kernel: exact fp32 products, no operand
+    pre-pass; d < 16 stays on the distance kernel), DALI_PAIRDIST_SMALL=0 keeps them on the persistent distance kernel: both are bit-exact
+    on small integers -- ragged row counts (751 = 23 x 32 + 15), a K that is no multiple of 16 (751: 46 whole steps + a masked one, rows
+    that are not 16-byte aligned), fewer k-steps than waves -- and agree with fp64 to fp32 grade on random rows."""
+    import os
+    from daliid_amd import _lib
+    g = torch.Generator().manual_seed(nq + 7 * ng + d)
+    q = torch.randint(-3, 4, (nq, d), generator=g).float()
+    gal = torch.randint(-3, 4, (ng, d), generator=g).float()
+    gal[:, 0] += torch.arange(ng).float() % 5
+    q[:, d - 1] -= torch.arange(nq).float() % 3
+    ref = q @ gal.t()
+    qr, gr = torch.randn(nq, d, generator=g), torch.randn(ng, d, generator=g)
+    ref_r = (qr.double() @ gr.double().t())
+    try:
+        for flag in ("1", "0"):
+            os.environ["DALI_PAIRDIST_SMALL"] = flag
+            _lib.lib().dali_debug_reload_env()
+            out = ops.pairdist(q.cuda(), gal.cuda(), metric="dot")
+            assert torch.equal(out.cpu(), ref), (flag, (out.cpu() - ref).abs().max())
+            out_r = ops.pairdist(qr.cuda(), gr.cuda(), metric="dot").cpu().double()
+            # exact fp32 products summed in fp32 on the small kernel; hi/lo split operands (the lo x lo product dropped, 2^-16 relative) otherwise
+            small = flag == "1" and d >= 16
+            rel = (out_r - ref_r).abs().max().item() / ref_r.abs().max().item()
+            assert rel <= (2e-6 if small else 5e-5), (flag, rel)
+    finally:
+        os.environ.pop("DALI_PAIRDIST_SMALL", None)
+        _lib.lib().dali_debug_reload_env()
+
+
 def test_pairdist_prepared_equals_one_shot(ops):
     g = torch.Generator().manual_seed(5)
     q = torch.randn(100, 256, generator=g).cuda()
