@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_distance/ (from scripts/profile_distance.sh) -> profiles/r01_distance_kernel_stats.{md,csv}."""
 import csv, os, shutil
-RND = os.environ.get("ROUND", "r04")
+RND = os.environ.get("ROUND", "r05")
 src = "gpurun_out/prof_distance"
 shutil.copy(src + "/kernel_stats.csv", "profiles/%s_distance_kernel_stats.csv" % RND)
 last = lambda f: open(src + "/" + f).read().strip().splitlines()[-1]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_<wl>/ (from scripts/profile_train.sh) -> profiles/<ROUND>_<wl>_* (committed summary)."""
 import csv, json, os, shutil, sys
-RND = os.environ.get("ROUND", "r04")
+RND = os.environ.get("ROUND", "r05")
 wl = sys.argv[1] if len(sys.argv) > 1 else "train"
 src, name = "gpurun_out/prof_%s" % wl, {"train": "train_step", "vit": "vit_step"}[wl]
 shutil.copy(src + "/pmc_traffic.json", "profiles/%s_%s_pmc_traffic.json" % (RND, wl))

@@ -5,4 +5,3 @@ DALI_GEMM_PROFILE_DUMP=gpurun_out/gemm_launches.csv timeout -k 10 200 python ben
 python scripts/gemm_launch_table.py gpurun_out/gemm_launches.csv 3 > gpurun_out/gemm_launch_table.txt
 python scripts/kstats.py gpurun_out/prof_train/stats 16 60 > gpurun_out/prof_train/kstats.txt
 bash scripts/profile_eval_forward.sh
-timeout -k 10 200 python scripts/bench_wgrad.py "" "DALI_WGRAD_ABLATE=1" "DALI_WGRAD_ABLATE=2" --filter c2 --reps 3 > gpurun_out/wgrad_ablate.log 2>&1
