@@ -430,7 +430,7 @@ def bench_train(args, world, rank):
     tflops = alg_flops / (k_ms * 1e-3) / 1e12
     traffic, traffic_source = committed_traffic("vit" if vit else "train")
     step_bytes, _ = committed_traffic("vit" if vit else "train", "all_kernels_hbm_bytes_per_step")     # the step is priced by both roofs
-    roofline = {"kernel": "igemm_conv_* + igemm_wgrad_* (implicit-GEMM MFMA kernels%s)" % ("; attention kernels not included" if vit else ""),
+    roofline = {"kernel": "igemm_conv_* + fused1x1_persist + igemm_wgrad_* (implicit-GEMM MFMA kernels%s)" % ("; attention kernels not included" if vit else ""),
                 "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches_per_step": int(k_launches), "kernel_ms_per_step": round(k_ms, 3),
