@@ -147,11 +147,13 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     const float* xr = x + (size_t)row * d;
     const float* gr = dy + (size_t)row * d;
     float ss = 0.f, xg = 0.f;
+#pragma unroll 8
     for (int c = lane; c < d; c += 64) { const float v = xr[c]; ss += v * v; xg += v * gr[c]; }
     ss = wave_sum(ss); xg = wave_sum(xg);
     const float nrm = sqrtf(ss), den = nrm + eps;
     const float a = 1.0f / den;
     const float b = (nrm > 0.f) ? xg / (nrm * den * den) : 0.f;
+#pragma unroll 8
     for (int c = lane; c < d; c += 64) dx[(size_t)row * d + c] = gr[c] * a - xr[c] * b;
 }
 
@@ -974,6 +976,8 @@ extern "C" int dali_pairdist_prepared(dali_ctx* ctx, void* stream, const void* q
 // (192-568 workgroups), its 4 waves split K in 16-deep steps (lane (i, h) takes k = k16 + 8h + t: two 16-byte loads per operand), D steps of
 // loads in flight ahead of each wave's MFMA chain, partial tiles summed through LDS in a fixed order.  Rows past nq / ng are clamped onto the
 // last row and masked at the store; k-steps past a wave's share are clamped and multiplied by zero; the K % 16 tail is one masked step.
+// (Rows are read in 16-byte pieces at 4-byte alignment when ldq / ldg is no multiple of 4 -- d = 751 in the heads' backward: global loads of any
+//  width need dword alignment only on gfx950; tests/test_gpu_eval.py covers that shape bit-exactly.)
 // ------------------------------------------------------------------------------------------------
 namespace dali {
 template <int D>

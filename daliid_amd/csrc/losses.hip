@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const float* __restric
     const float* s = S + (size_t)i * NC;
     float m = -__builtin_inff();
     int am = 0;
+#pragma unroll 4
     for (int j = lane; j < NC; j += 64) { const float v = s[j] * inv_tau; if (v > m) { m = v; am = j; } }
     // wave arg-max (first index on ties)
 #pragma unroll
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const float* __restric
     float se = 0.f, pos = 0.f;
     int cnt = 0;
     const int yi = y[i];
+#pragma unroll 4
     for (int j = lane; j < NC; j += 64) {
         const float v = s[j] * inv_tau;
         se += expf(v - m);
@@ -103,11 +105,17 @@ __global__ __launch_bounds__(256) void center_bwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int PROXY_KMAX = 16;
 
+// Rows of up to 256 * PROXY_RV proxies are held in registers (one read of S and of the labels; every round of the top-k selection and the
+// positives' values came from global memory before: ~10 dependent passes over the row, 61 us per launch at 256 x 2253); longer rows take the
+// same code with the values re-read per round.
+constexpr int PROXY_RV = 16;
+
 __global__ __launch_bounds__(256) void proxy_rows_kernel(const float* __restrict__ S, const int32_t* __restrict__ y,
                                                           const int32_t* __restrict__ pl, const float* __restrict__ w, float inv_tau,
                                                           int nb, int NP, float* __restrict__ rowstat, int32_t* __restrict__ sel_idx,
                                                           float* __restrict__ sel_coef, int32_t* __restrict__ status) {
     __shared__ int s_pos[PROXY_KMAX];
+    __shared__ float s_posv[PROXY_KMAX];
     __shared__ int s_npos;
     __shared__ float s_rv[4];
     __shared__ int s_ri[4];
@@ -116,12 +124,36 @@ __global__ __launch_bounds__(256) void proxy_rows_kernel(const float* __restrict
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* s = S + (size_t)i * NP;
     const int yi = y[i];
+    const bool in_regs = NP <= 256 * PROXY_RV;
     if (tid == 0) s_npos = 0;
     __syncthreads();
-    for (int j = tid; j < NP; j += 256) {
-        if (pl[j] == yi) {
-            const int slot = atomicAdd(&s_npos, 1);
-            if (slot < PROXY_KMAX) s_pos[slot] = j;
+    // negatives' values of this thread (entries tid, tid + 256, ...); positives and entries past the row are -inf: never picked, since at most
+    // min(n, NP - n) negatives are asked for
+    float rv[PROXY_RV];
+    if (in_regs) {
+        float val[PROXY_RV];
+        int lab[PROXY_RV];
+#pragma unroll
+        for (int u = 0; u < PROXY_RV; ++u) {
+            const int jc = min(tid + 256 * u, NP - 1);              // clamped: unconditional loads, all in flight together
+            val[u] = s[jc]; lab[u] = pl[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < PROXY_RV; ++u) {
+            const int j = tid + 256 * u;
+            const bool pos = j < NP && lab[u] == yi;
+            if (pos) {
+                const int slot = atomicAdd(&s_npos, 1);
+                if (slot < PROXY_KMAX) { s_pos[slot] = j; s_posv[slot] = val[u]; }
+            }
+            rv[u] = (j < NP && !pos) ? val[u] : -__builtin_inff();
+        }
+    } else {
+        for (int j = tid; j < NP; j += 256) {
+            if (pl[j] == yi) {
+                const int slot = atomicAdd(&s_npos, 1);
+                if (slot < PROXY_KMAX) { s_pos[slot] = j; s_posv[slot] = s[j]; }
+            }
         }
     }
     __syncthreads();
@@ -136,7 +168,12 @@ __global__ __launch_bounds__(256) void proxy_rows_kernel(const float* __restrict
     }
     // deterministic order of the positives (ascending index): tiny insertion sort by one thread
     if (tid == 0) {
-        for (int a = 1; a < n; ++a) { const int v = s_pos[a]; int b = a - 1; while (b >= 0 && s_pos[b] > v) { s_pos[b + 1] = s_pos[b]; --b; } s_pos[b + 1] = v; }
+        for (int a = 1; a < n; ++a) {
+            const int v = s_pos[a]; const float f = s_posv[a];
+            int b = a - 1;
+            while (b >= 0 && s_pos[b] > v) { s_pos[b + 1] = s_pos[b]; s_posv[b + 1] = s_posv[b]; --b; }
+            s_pos[b + 1] = v; s_posv[b + 1] = f;
+        }
     }
     __syncthreads();
     // top-n negatives: n rounds of block arg-max over keys strictly below the previous pick ((value desc, index asc) order)
@@ -147,11 +184,21 @@ __global__ __launch_bounds__(256) void proxy_rows_kernel(const float* __restrict
     for (int t = 0; t < k; ++t) {
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
-        for (int j = tid; j < NP; j += 256) {
-            if (pl[j] == yi) continue;
-            const float v = s[j];
-            const bool below_prev = (v < pv) || (v == pv && j > pi);
-            if (below_prev && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < PROXY_RV; ++u) {
+                const int j = tid + 256 * u;
+                const float v = rv[u];
+                const bool below_prev = (v < pv) || (v == pv && j > pi);
+                if (v > -__builtin_inff() && below_prev && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
+            }
+        } else {
+            for (int j = tid; j < NP; j += 256) {
+                if (pl[j] == yi) continue;
+                const float v = s[j];
+                const bool below_prev = (v < pv) || (v == pv && j > pi);
+                if (below_prev && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -173,17 +220,17 @@ __global__ __launch_bounds__(256) void proxy_rows_kernel(const float* __restrict
     if (tid == 0) {
         // exponentials relative to the max selected value (stable); everything is <= 2*PROXY_KMAX terms
         float m = -__builtin_inff();
-        for (int a = 0; a < n; ++a) m = fmaxf(m, s[s_pos[a]] * inv_tau);
+        for (int a = 0; a < n; ++a) m = fmaxf(m, s_posv[a] * inv_tau);
         for (int a = 0; a < k; ++a) m = fmaxf(m, s_negv[a] * inv_tau);
         float D = 0.f, possum = 0.f;
-        for (int a = 0; a < n; ++a) { const float v = s[s_pos[a]] * inv_tau; D += expf(v - m); possum += v; }
+        for (int a = 0; a < n; ++a) { const float v = s_posv[a] * inv_tau; D += expf(v - m); possum += v; }
         for (int a = 0; a < k; ++a) D += expf(s_negv[a] * inv_tau - m);
         const float logD = m + logf(D);
         const float wi = w[i];
         rowstat[i * 2] = -wi * (possum / (float)n - logD);
         rowstat[i * 2 + 1] = wi;
         for (int a = 0; a < PROXY_KMAX; ++a) {
-            if (a < n) { si[a] = s_pos[a]; sc[a] = wi * inv_tau * (expf(s[s_pos[a]] * inv_tau - logD) - 1.0f / (float)n); }
+            if (a < n) { si[a] = s_pos[a]; sc[a] = wi * inv_tau * (expf(s_posv[a] * inv_tau - logD) - 1.0f / (float)n); }
             else { si[a] = -1; sc[a] = 0.f; }
             if (a < k) { si[PROXY_KMAX + a] = s_negi[a]; sc[PROXY_KMAX + a] = wi * inv_tau * expf(s_negv[a] * inv_tau - logD); }
             else { si[PROXY_KMAX + a] = -1; sc[PROXY_KMAX + a] = 0.f; }
@@ -199,13 +246,20 @@ __global__ __launch_bounds__(256) void proxy_bwd_kernel(const int32_t* __restric
     const int32_t* si = sel_idx + (size_t)i * 2 * PROXY_KMAX;
     const float* sc = sel_coef + (size_t)i * 2 * PROXY_KMAX;
     const float z = gscale / denom[0];
+    // the row's <= 2 K selected proxies once, in registers; an empty slot reads proxy 0 with coefficient 0 (a predicate per slot put every load of
+    // the gather behind its own branch and wait: 34 us for 256 x 32 rows of 8 KB)
+    int jj[2 * PROXY_KMAX];
+    float cf[2 * PROXY_KMAX];
+#pragma unroll
+    for (int a = 0; a < 2 * PROXY_KMAX; ++a) {
+        const int j = si[a];
+        jj[a] = j < 0 ? 0 : j;
+        cf[a] = j < 0 ? 0.f : sc[a];
+    }
     for (int d = threadIdx.x; d < D; d += 256) {
         float acc = 0.f;
-#pragma unroll 4
-        for (int a = 0; a < 2 * PROXY_KMAX; ++a) {
-            const int j = si[a];
-            if (j >= 0) acc += sc[a] * P[(size_t)j * D + d];
-        }
+#pragma unroll
+        for (int a = 0; a < 2 * PROXY_KMAX; ++a) acc += cf[a] * P[(size_t)jj[a] * D + d];
         acc *= z;
         dfn[(size_t)i * D + d] = accumulate ? dfn[(size_t)i * D + d] + acc : acc;
     }

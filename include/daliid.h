@@ -71,7 +71,10 @@ int dali_l2norm_rows_bwd(dali_ctx* ctx, void* stream, const float* x, const floa
 /* out[nq,ng] (fp32, row-major) = metric(Q[nq,d], G[ng,d]); fp32 inputs.
  * normalize != 0 fuses the row normalisation of validateModels.py:41-42 into the operand pre-pass
  * (the reference sequence normalise -> 1 - q@g.T becomes one call).
- * Workspace: the two operand images (dali_pairdist_operand_bytes) + (nq+ng)*4. */
+ * Workspace: the two operand images (dali_pairdist_operand_bytes) + (nq+ng)*4.
+ * DALI_METRIC_DOT at DALI_PREC_BF16X3 without normalisation on a problem that would fill at most a quarter of the CUs with 128 x 256 tiles
+ * (the loss heads' similarity GEMMs, losses.py:62, :277) runs on the fp32 matrix cores instead: exact fp32 products, no operand images, no
+ * workspace; Q and G need 4-byte alignment only (any d). */
 int dali_pairdist(dali_ctx* ctx, void* stream, const float* Q, const float* G, int nq, int ng, int d,
                   int metric, int precision, int normalize, float* out);
 
