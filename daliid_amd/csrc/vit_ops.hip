@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_bwd_kernel(const uint16_t
     if (i >= T * cpr) return;
     const int c = (i % cpr) * 8, t = i / cpr;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int b = 0; b < B; ++b) {
         const uint4 raw = *reinterpret_cast<const uint4*>(dx + ((size_t)b * T + t) * C + c);
         float v[8];
