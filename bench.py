@@ -533,6 +533,19 @@ def bench_epoch(args, world, rank):
         torch.cuda.synchronize()
         t_inf = max_over_ranks(time.perf_counter() - t0, world)
         rows_this_rank = getattr(tr, "last_inference_rows", N) if world > 1 else N
+        # (1b) the forward alone on one resident batch of 500 (no loader, no gather from the pool, no concatenation): what the kernels do
+        xb = pool[:500].contiguous()
+        online.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                online(xb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                online(xb)
+            torch.cuda.synchronize()
+        t_fwd = (time.perf_counter() - t0) / 10
+        del xb
         # (2) centers + proxies alone
         np.random.seed(12)
         T.build_centers_and_proxies(fvs, labels, 5); torch.cuda.synchronize()
@@ -560,6 +573,9 @@ def bench_epoch(args, world, rank):
                                    % (N, NID, steps, 2 * P * K, P, K)},
             "inference_images_per_s": round(N / t_inf, 1), "inference_s": round(t_inf, 3), "inference_rows_per_rank": int(rows_this_rank),
             "inference_images_per_s_per_rank": round(rows_this_rank / t_inf, 1),
+            "inference_forward_only": {"images_per_s": round(500 / t_fwd, 1), "ms_per_batch": round(t_fwd * 1e3, 3),
+                                       "note": "the eval-mode forward on one resident batch of 500; inference_images_per_s above adds the pool gather, "
+                                               "the ragged last batch and the concatenation of extractFeatures"},
             "targets_ms": round(t_tgt * 1e3, 2),
             "pk_steps": steps, "pk_loop_s": round(t_loop, 3), "pk_images_per_s": round(world * steps * 2 * P * K / max(t_loop, 1e-9), 1),
             "mean_loss": float(st["loss"]),
