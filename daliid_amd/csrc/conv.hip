@@ -2608,6 +2608,18 @@ struct ProfScope {
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof->ev[2 * i + 1], st); }
 };
 
+// the same bracket for GEMM launches that live in other translation units (stem.hip): -> slot index, or -1 when no profile step is running
+int gemm_profile_begin(hipStream_t st, int cls, double flops, const char* what) {
+    if (!g_prof || g_prof->used >= g_prof->cap) return -1;
+    const size_t i = g_prof->used++;
+    g_prof->cls[i] = cls; g_prof->flops[i] = flops; g_prof->desc[i] = what;
+    (void)hipEventRecord(g_prof->ev[2 * i], st);
+    return (int)i;
+}
+void gemm_profile_end(hipStream_t st, int slot) {
+    if (slot >= 0 && g_prof) (void)hipEventRecord(g_prof->ev[2 * slot + 1], st);
+}
+
 // Host-side launchers shared with the net plan (resnet_plan.hip).
 static int launch_igemm_conv_one(hipStream_t st, const IGemmArgs& a);
 static bool narrow_cm(int Cm) { return Cm <= 64; }

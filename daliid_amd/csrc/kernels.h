@@ -89,6 +89,9 @@ struct BnBwdSide { const uint16_t* raw; const float* mean; const float* invstd; 
 
 // conv.hip
 int launch_igemm_conv(hipStream_t st, const IGemmArgs& a);
+// per-launch event bracket of the GEMM profile steps (dali_gemm_profile_*), for GEMM launches outside conv.hip; cls 0 = forward / data gradient
+int gemm_profile_begin(hipStream_t st, int cls, double flops, const char* what);
+void gemm_profile_end(hipStream_t st, int slot);
 int igemm_conv_stat_tiles(int Cm, int P, int K);
 bool conv_cat_act_supported(int Cm, int c1, int c2, int P, int parts = 1);      // [X | X2] GEMM with the scale / shift / ReLU output stage at this size?
 // taps = R*S of the convolution (1 for 1x1 convolutions and linear layers): selects the tile shape
@@ -151,6 +154,10 @@ int launch_stem_pack_image(hipStream_t st, const float* img, int N, int H, int W
 int launch_stem_pack_weight(hipStream_t st, const float* w, int Cout, uint16_t* out);
 // stem.hip: the inference stem (conv1 -> bn1 by running statistics -> 3x3 / 2 max-pool) in one launch, packed image -> pooled [N][H/4][W/4][64]
 bool stem_fused_supported(int N, int H, int W, int C);
+// the training stem convolution (raw0 + per-tile BatchNorm partial sums [stem_train_tiles][64][2]) on the same patch machinery
+bool stem_train_supported(int N, int H, int W, int C);
+int stem_train_tiles(int N, int H);
+int launch_stem_conv_stats(hipStream_t st, const uint16_t* ximg, const uint16_t* w_packed, int N, int H, int W, uint16_t* raw, float* stats);
 int launch_stem_conv_bn_pool(hipStream_t st, const uint16_t* ximg, const uint16_t* w_packed, const float* scale, const float* shift, int N, int H, int W,
                              uint16_t* out);
 int launch_stem_unpack_wgrad(hipStream_t st, const float* padded, int Cout, float* dw);

@@ -490,7 +490,11 @@ extern "C" int dali_resnet_forward(dali_resnet* net, void* stream, const float* 
         // inference: one launch, the convolution's output never stored (stem.hip); bn1 acts on the fp32 accumulators
         if ((rc = launch_stem_conv_bn_pool(st, net->ximg, net->w_stem, net->stem_bn.scale, net->stem_bn.shift, net->N, net->H, net->W, net->pool0))) return rc;
     } else {
-    {
+    if (tr && stem_train_supported(net->N, net->H, net->W, net->stem.cout)) {
+        // training: raw0 + the statistics' partial sums from the patch kernel (stem.hip), 256-pixel tiles as the implicit-GEMM kernel's slab
+        if ((rc = launch_stem_conv_stats(st, net->ximg, net->w_stem, net->N, net->H, net->W, net->raw0, net->stat_partial))) return rc;
+        if ((rc = bn_train(net, st, net->stem_bn, stem_train_tiles(net->N, net->H), (double)net->N * net->stem_h * net->stem_w))) return rc;
+    } else {
         IGemmArgs a{};
         a.W = net->w_stem; a.X = net->ximg; a.O = net->raw0; a.Res = nullptr; a.in_scale = nullptr; a.in_shift = nullptr; a.in_relu = 0;
         a.stats = tr ? net->stat_partial : nullptr;

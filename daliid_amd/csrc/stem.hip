@@ -220,6 +220,128 @@ __global__ __launch_bounds__(SF_THREADS, 2) void stem_conv_bn_pool_kernel(StemAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Training stem convolution: raw0 = conv1(images) (bf16 [N][H/2][W/2][64]) + per-tile partial BatchNorm sums (sum, sum of squares of the fp32
+// accumulators, [tiles][64][2] as the implicit-GEMM kernels leave them for reduce_finish).  Same machinery as above (packed rows in an LDS patch,
+// B fragments straight from it, weights in registers, two workgroups per CU); a tile is 4 convolution rows of one image: no halo, 13 packed rows.
+// The 64 x 256 tile of the implicit-GEMM kernel ran this shape (K = 224: 7 k-steps per tile) at 160 us for 341 MB.  W = 128 only (256 pixels per
+// tile = the statistics slab's row count the plan reserves).
+// ------------------------------------------------------------------------------------------------
+struct StemTrainArgs {
+    const uint16_t* ximg; const uint16_t* w; uint16_t* raw; float* stats;
+    int N, Hp, Wp, Hc, Wc, tiles;                // tiles = N * Hc / 4
+};
+constexpr int ST_PATCH_ROWS = 13, ST_CONV_ROWS = 4;
+__device__ __forceinline__ float st_row16_sum(float v) {          // sum over the 16 lanes of a DPP row, in every lane of the row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+__global__ __launch_bounds__(SF_THREADS, 2) void stem_conv_stats_kernel(StemTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, n16 = lane & 15;
+    const int row_bytes = a.Wp * 8;
+    const int nchunks = ST_PATCH_ROWS * row_bytes >> 4;
+    constexpr int patch_pitch = SF_THREADS * SF_NST * 16;
+    unsigned char* rtile = sf_smem + 2 * patch_pitch;              // [patch 0 | patch 1 | raw tile 256 px x 128 B | statistics 4 waves x 128 floats]
+    float* wstat = reinterpret_cast<float*>(rtile + ST_CONV_ROWS * a.Wc * 128);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.ximg), 0, a.N * a.Hp * row_bytes, 0x00020000);
+    bf16x8_t A[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int co = 16 * (n16 >> 2) + 4 * i + (n16 & 3);
+            A[i][r] = *reinterpret_cast<const bf16x8_t*>(a.w + co * 224 + r * 32 + q * 8);
+        }
+    const int tiles_per_img = a.Hc >> 2;
+    auto request = [&](int t, uint4 (&st)[SF_NST]) {               // packed rows 8 r4 .. 8 r4 + 12 of image n: one contiguous range
+        const int n = t / tiles_per_img, r4 = t - n * tiles_per_img;
+        const int base = (n * a.Hp + 8 * r4) * row_bytes;
+#pragma unroll
+        for (int s = 0; s < SF_NST; ++s) {
+            const int c = tid + SF_THREADS * s;
+            const uint32_t off = (uint32_t)(base + c * 16) | (c < nchunks ? 0u : DMA_OOB);
+            st[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+        }
+    };
+    auto deposit = [&](unsigned char* patch, const uint4 (&st)[SF_NST]) {
+#pragma unroll
+        for (int s = 0; s < SF_NST; ++s) *reinterpret_cast<uint4*>(patch + (tid + SF_THREADS * s) * 16) = st[s];
+    };
+    uint4 st[SF_NST];
+    int t = blockIdx.x;
+    if (t < a.tiles) { request(t, st); deposit(sf_smem, st); }
+    if (t + (int)gridDim.x < a.tiles) request(t + gridDim.x, st);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) asm volatile("" : "+v"(A[i][r]));
+    const int gpr = a.Wc >> 4, ngroups = ST_CONV_ROWS * gpr;
+    int buf = 0;
+    for (; t < a.tiles; t += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* patch = sf_smem + buf * patch_pitch;
+        const bool more = t + (int)gridDim.x < a.tiles;
+        float s1[16], s2[16];                                      // this lane's pixel column of the tile: sums over its groups, channels 16 q + e
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        for (int g = wave; g < ngroups; g += 4) {
+            const int cr = g / gpr, wc0 = (g - cr * gpr) * 16;
+            const unsigned char* b0 = patch + (2 * cr) * row_bytes + (wc0 + n16 + q) * 16;
+            bf16x8_t B[7];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) B[r] = *reinterpret_cast<const bf16x8_t*>(b0 + r * row_bytes);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i][r], B[r], acc[i], 0, 0, 0);
+            const int px = cr * a.Wc + wc0 + n16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t k[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int e = 8 * h + 2 * p;
+                    const float v0 = acc[e >> 2][e & 3], v1 = acc[(e + 1) >> 2][(e + 1) & 3];
+                    s1[e] += v0; s2[e] += v0 * v0; s1[e + 1] += v1; s2[e + 1] += v1 * v1;
+                    k[p] = pack_bf16x2(v0, v1);
+                }
+                *reinterpret_cast<uint4*>(rtile + px * 128 + (((2 * q + h) ^ (px & 7)) << 4)) = make_uint4(k[0], k[1], k[2], k[3]);
+            }
+        }
+        // the wave's share of the tile's sums: over its 16 pixel columns (DPP row), one writer per lane group
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1[e] = st_row16_sum(s1[e]); s2[e] = st_row16_sum(s2[e]); }
+        if (n16 == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { wstat[wave * 128 + (16 * q + e) * 2] = s1[e]; wstat[wave * 128 + (16 * q + e) * 2 + 1] = s2[e]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) deposit(sf_smem + (buf ^ 1) * patch_pitch, st);
+        if (t + 2 * (int)gridDim.x < a.tiles) request(t + 2 * gridDim.x, st);
+        asm volatile("" ::: "memory");
+        // ---- the tile leaves as one contiguous range of raw0 (4 whole rows of one image), the sums as one row of the statistics slab ----
+        uint16_t* dst = a.raw + (size_t)t * (ST_CONV_ROWS * a.Wc * 64);
+        for (int c = tid; c < ST_CONV_ROWS * a.Wc * 8; c += SF_THREADS) {
+            const int px = c >> 3, cc = c & 7;
+            *reinterpret_cast<uint4*>(dst + (size_t)c * 8) = *reinterpret_cast<const uint4*>(rtile + px * 128 + ((cc ^ (px & 7)) << 4));
+        }
+        if (tid < 128) a.stats[(size_t)t * 128 + tid] = ((wstat[tid] + wstat[128 + tid]) + wstat[256 + tid]) + wstat[384 + tid];
+    }
+}
+
 int stem_cu_count() {
     static int n_cus = 0;
     if (!n_cus) {
@@ -231,6 +353,32 @@ int stem_cu_count() {
 }
 
 }  // namespace
+
+// the training stem convolution on the patch kernel: 64 channels, W = 128 (256-pixel tiles: the statistics slab the plan reserves), H % 8 == 0
+bool stem_train_supported(int N, int H, int W, int C) {
+    if (C != 64 || W != 128 || H % 8 != 0) return false;
+    if ((long long)N * (H + 6) * (W + 8) * 8 >= 0x7ff00000ll) return false;
+    return DALI_ENV_INT("DALI_TRAIN_STEM", 1) != 0;
+}
+int stem_train_tiles(int N, int H) { return N * (H / 2 / 4); }
+int launch_stem_conv_stats(hipStream_t st, const uint16_t* ximg, const uint16_t* w, int N, int H, int W, uint16_t* raw, float* stats) {
+    if (!stem_train_supported(N, H, W, 64)) { set_error("stem_conv_stats: unsupported shape %d x %d x %d", N, H, W); return DALI_ERR_INVALID; }
+    StemTrainArgs a{};
+    a.ximg = ximg; a.w = w; a.raw = raw; a.stats = stats;
+    a.N = N; a.Hp = H + 6; a.Wp = W + 8; a.Hc = H / 2; a.Wc = W / 2; a.tiles = stem_train_tiles(N, H);
+    const int lds = 2 * SF_THREADS * SF_NST * 16 + ST_CONV_ROWS * a.Wc * 128 + 4 * 128 * 4;
+    DALI_ONCE_PER_DEVICE(DALI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)));
+    const int n_cus = stem_cu_count();
+    if (n_cus <= 0) { set_error("stem_conv_stats: device query failed"); return DALI_ERR_HIP; }
+    const int grid = a.tiles < 2 * n_cus ? a.tiles : 2 * n_cus;
+    char what[160];
+    snprintf(what, sizeof what, "fwd,Cm=64,K=224,P=%d,taps=7,stride=2,sub=0,fused=0,stats=1,res=0,mask=0,lin=0", N * a.Hc * a.Wc);
+    const int slot = gemm_profile_begin(st, 0, 2.0 * 64 * 224 * (double)N * a.Hc * a.Wc, what);     // counted with the GEMM launches, as the kernel it replaces
+    hipLaunchKernelGGL(stem_conv_stats_kernel, dim3(grid), dim3(SF_THREADS), lds, st, a);
+    gemm_profile_end(st, slot);
+    DALI_LAUNCH_CHECK();
+    return DALI_OK;
+}
 
 // 64 output channels, an input the packed-row staging covers with 4 requests per thread, a pixel grid in whole groups of 16 columns
 bool stem_fused_supported(int N, int H, int W, int C) {

@@ -81,3 +81,38 @@ def test_net_plan_inference_stem_equals_the_three_launch_form():
     assert outs["1"].abs().max() > 0 and outs["1"].std() > 0.01
     assert torch.equal(outs["1"], outs["0"])
     assert torch.equal(embs["1"], embs["0"])
+
+
+@pytest.mark.parametrize("n,h", [(3, 64), (40, 256)])
+def test_training_stem_convolution_and_statistics_exact_integers(n, h):
+    """Training forward at width 64 and W = 128: conv1's output and the BatchNorm partial sums come from the patch kernel (stem.hip,
+    stem_conv_stats_kernel; DALI_TRAIN_STEM=0 keeps the implicit-GEMM launch).  Integer images and weights: raw0 equals torch's CPU
+    convolution bit for bit, the batch mean / variance (fp32 partial sums per wave and tile, fixed-order sums, fp64 finish) equal the exact
+    ones to fp32 rounding; the two paths give identical raw0 and identical statistics' consumers (pool0) -- also with more tiles than
+    resident workgroups (n = 40: 1280 tiles on 512 workgroups)."""
+    from daliid_amd import Encoders, _lib
+    g = torch.Generator().manual_seed(77 + n)
+    net = Encoders.ResNet50ReID(layers=(1, 1, 1, 1), seed=3)
+    sd = net.state_dict()
+    sd["conv1.weight"] = torch.randint(-2, 3, tuple(sd["conv1.weight"].shape), generator=g).float().cuda()
+    net.load_state_dict(sd)
+    x = torch.randint(-3, 4, (n, 3, h, 128), generator=g).float()
+    ref_raw0 = F.conv2d(x, sd["conv1.weight"].cpu(), stride=2, padding=3).permute(0, 2, 3, 1).contiguous()      # exact integers
+    outs = {}
+    for flag in ("1", "0"):
+        os.environ["DALI_TRAIN_STEM"] = flag
+        _lib.lib().dali_debug_reload_env()
+        net.train()
+        with torch.no_grad():
+            net(x.cuda())
+        raw0 = net.debug_tensor("raw0", bf16, (n, h // 2, 64, 64)).float().cpu()
+        mean = net.debug_tensor("bn1.mean", torch.float32, (64,)).cpu()
+        pool0 = net.debug_tensor("pool0", bf16, (n, h // 4, 32, 64)).float().cpu()
+        outs[flag] = (raw0, mean, pool0)
+    os.environ.pop("DALI_TRAIN_STEM")
+    _lib.lib().dali_debug_reload_env()
+    want = ref_raw0.to(bf16).float()
+    for flag in ("1", "0"):
+        assert torch.equal(outs[flag][0], want), flag
+        assert torch.allclose(outs[flag][1].double(), ref_raw0.double().mean((0, 1, 2)), rtol=1e-6, atol=1e-6), flag
+    assert torch.equal(outs["1"][2], outs["0"][2])
